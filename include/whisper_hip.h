@@ -1,0 +1,178 @@
+/*
+ * whisper_hip.h — C ABI of the MI355X-native Whisper hot path (libwhisper_hip.so).
+ *
+ * Drop-in boundary for KrArunT/whisper-rust-ort's one hot path
+ *     clip -> log-mel -> encoder -> greedy decoder with KV past -> token ids.
+ * The reference has no plugin API; the seam is three Rust functions plus the ONNX Runtime
+ * session lifecycle in src/main.rs.  Each entry point below names the reference interface it
+ * replaces (file:line in /root/reference).  INTEGRATION.md shows the Rust `extern "C"` block a
+ * maintainer would add to bind them.
+ *
+ * Conventions
+ *   - plain C: opaque handles, pointers and sizes only; no C++/torch types cross the ABI.
+ *   - every function returns an int status (WH_OK == 0); nothing throws or aborts across the ABI.
+ *     wh_last_error() gives the message of the last failure on a ctx (or globally for load errors).
+ *     The reference's three `bail!` preconditions map to distinct codes (WH_ERR_EMPTY_AUDIO,
+ *     WH_ERR_BAD_SHAPE, WH_ERR_STATE).
+ *   - caller owns every host buffer in and out (outputs are caller-allocated with explicit
+ *     capacities); the library owns device weights (wh_model) and per-stream workspaces + KV
+ *     caches (wh_ctx).  Only the two handle types need a library-side free.
+ *   - wh_model is immutable after load and may be shared by any number of wh_ctx / host threads
+ *     (reference: `&Session` shared across the rayon pool, src/main.rs:890-919).  A wh_ctx is
+ *     single-threaded and bound to one HIP stream (reference: per-thread IoBinding + `past` map,
+ *     src/main.rs:786-791).
+ *   - there is NO CPU fallback: every compute entry point needs a gfx950 device and fails with
+ *     WH_ERR_HIP otherwise.
+ */
+#ifndef WHISPER_HIP_H
+#define WHISPER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WH_ABI_VERSION 1
+
+/* status codes */
+#define WH_OK 0
+#define WH_ERR_EMPTY_AUDIO 1 /* src/main.rs:414-416  bail!("Empty audio") */
+#define WH_ERR_BAD_SHAPE 2   /* src/main.rs:710-716  bail!("Unexpected logits shape") / bad mel shape */
+#define WH_ERR_STATE 3       /* src/main.rs:808-810  bail!("Missing cached decoder input"): decode before encode */
+#define WH_ERR_ARG 4
+#define WH_ERR_NOMEM 5
+#define WH_ERR_HIP 6         /* no device / HIP runtime error / kernel image missing */
+#define WH_ERR_IO 7          /* model dir, config.json, safetensors */
+#define WH_ERR_UNSUPPORTED 8
+
+/* arithmetic type of the Linear/conv/attention contractions */
+#define WH_PREC_F32 0  /* exact-f32 MFMA (v_mfma_f32_16x16x4_f32): the token-for-token / 1e-3-logit mode */
+#define WH_PREC_BF16 1 /* bf16 MFMA, f32 accumulate, f32 residual stream: the throughput mode */
+
+#define WH_N_FRAMES 3000      /* mel frames per 30 s window (src/main.rs:896) */
+#define WH_CLIP_SAMPLES 480000 /* 30 s @ 16 kHz */
+
+typedef struct wh_model wh_model;
+typedef struct wh_ctx wh_ctx;
+
+/* Geometry read from config.json (HF WhisperConfig field names in comments). */
+typedef struct {
+    int32_t n_mels;      /* num_mel_bins */
+    int32_t d_model;     /* d_model */
+    int32_t n_heads;     /* encoder_attention_heads == decoder_attention_heads; head_dim must be 64 */
+    int32_t enc_layers;  /* encoder_layers */
+    int32_t dec_layers;  /* decoder_layers */
+    int32_t ffn;         /* encoder_ffn_dim == decoder_ffn_dim */
+    int32_t vocab;       /* vocab_size */
+    int32_t n_audio_ctx; /* max_source_positions (1500) */
+    int32_t n_text_ctx;  /* max_target_positions (448) */
+} wh_dims;
+
+/* Stage timings of the last transcribe call on a ctx, in seconds — the reference's `Timing`
+ * buckets (src/main.rs:1010-1016) measured with HIP events on the ctx stream. */
+typedef struct {
+    double preprocess_s; /* log-mel                       (src/main.rs:870-872) */
+    double encode_s;     /* encoder                        } both are the reference's model_only_s */
+    double decode_s;     /* cross-KV + greedy token loop   } (src/main.rs:964-967)                 */
+    double total_s;      /* first H2D to last D2H, host wall clock */
+    double h2d_s, d2h_s;
+} wh_timing;
+
+/* Greedy-decode parameters: the arguments of greedy_decode_with_past (src/main.rs:753-761) with
+ * GenerationCfg (src/main.rs:102-106) flattened. */
+typedef struct {
+    const int64_t* prompt;         /* [n_prompt] — sot, lang, task, (notimestamps)  src/main.rs:851-855 */
+    size_t n_prompt;
+    size_t max_new_tokens;         /* --max-new-tokens; total generated ≤ this (src/main.rs:793) */
+    int64_t eot;                   /* stop token (src/main.rs:781,820) */
+    const int64_t* suppress;       /* generation_config.json suppress_tokens        (src/main.rs:765) */
+    size_t n_suppress;
+    const int64_t* begin_suppress; /* begin_suppress_tokens: first generated token only (766-768,778) */
+    size_t n_begin_suppress;
+    /* parity harness only (NULL/0 in production): generated token i is replaced by forced[i] as the
+     * next input AFTER the argmax has been recorded, and EOT does not stop a forced step. */
+    const int64_t* forced;
+    size_t n_forced;
+} wh_decode_params;
+
+/* ---- model lifecycle: replaces build_session ×3 (src/main.rs:169-202, 1099-1108) ------------- */
+/* `model_dir_or_spec` is what the CLI's --onnx-dir names: a directory holding config.json +
+ * model.safetensors (HF layout), or the literal spec "synthetic:<preset>:<seed>" with preset in
+ * {nano, micro, base, large-v3} for hash-seeded weights (whisper-rust-ort_amd/modelspec.py). */
+int wh_model_load(const char* model_dir_or_spec, int device, int precision, wh_model** out);
+/* Same, from a caller-held f32 blob in canonical tensor order (modelspec.tensor_table). */
+int wh_model_create(const wh_dims* dims, const float* weights, size_t n_weights, int device, int precision,
+                    wh_model** out);
+void wh_model_free(wh_model* m);
+int wh_model_get_dims(const wh_model* m, wh_dims* out);
+int wh_model_precision(const wh_model* m);
+/* Copies the f32 master copy of one tensor (HF state-dict name) to `out`; *n_out = element count.
+ * Used to check the C++ synthetic generator against the numpy one. */
+int wh_model_export_tensor(const wh_model* m, const char* name, float* out, size_t cap, size_t* n_out);
+
+/* ---- per-stream context: workspace + KV cache for up to max_batch clips in flight ------------- */
+int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out);
+void wh_ctx_free(wh_ctx* c);
+const char* wh_last_error(const wh_ctx* c); /* c == NULL: last load/create error of this thread */
+int wh_get_timings(const wh_ctx* c, wh_timing* out);
+
+/* ---- staged calls: the reference's three functions, one clip each ----------------------------- */
+/* whisper_log_mel_80 (src/main.rs:407-509), n_mels taken from the model.  `pcm` is the WHOLE file
+ * (any n ≥ 1): n_frames = wh_mel_frames(n); normalisation uses the global max over all frames.
+ * mel_out: [n_mels][n_frames] row-major (mel-major), caller-allocated, cap_frames ≥ n_frames. */
+size_t wh_mel_frames(size_t n_samples); /* src/main.rs:444-452 */
+int wh_log_mel(wh_ctx* c, const float* pcm, size_t n_samples, float* mel_out, size_t cap_frames,
+               size_t* n_frames_out);
+/* run_encoder (src/main.rs:698-707): mel [n_mels][3000] host f32 → encoder states.  enc_out
+ * ([n_audio_ctx][d_model] f32) may be NULL: the states always stay resident in the ctx for decode. */
+int wh_encode(wh_ctx* c, const float* mel, float* enc_out);
+/* greedy_decode_with_past (src/main.rs:753-829) on the encoder states held by the ctx.
+ * tokens_out: prompt ++ generated (EOT included if hit), capacity n_prompt + max_new_tokens.
+ * logits_out (optional, parity): [n_generated][vocab] f32, row i = logits that chose generated token i. */
+int wh_decode_greedy(wh_ctx* c, const wh_decode_params* p, int64_t* tokens_out, size_t cap_tokens,
+                     size_t* n_tokens_out, float* logits_out, size_t cap_logits_rows);
+
+/* ---- fused batch call: the body of transcribe_longform_chunked for ≤ max_batch single-window
+ * clips (src/main.rs:870-915 / 946-967) run as one batch on the ctx stream -------------------- */
+typedef struct {
+    const float* pcm;  /* 16 kHz mono f32 */
+    size_t n_samples;  /* 1 … 480000; shorter clips are zero-padded in normalised mel space (899-905) */
+} wh_clip;
+/* tokens_out: [n_clips][n_prompt + max_new_tokens] row-major; n_tokens_out: [n_clips]. */
+int wh_transcribe_batch(wh_ctx* c, const wh_clip* clips, size_t n_clips, const wh_decode_params* p,
+                        int64_t* tokens_out, size_t* n_tokens_out);
+/* Same with PCM already resident in device memory: d_pcm is [n_clips][480000] f32 on the ctx's
+ * device (each clip exactly 30 s).  This is the entry bench.py times (inputs resident in HBM). */
+int wh_transcribe_batch_device(wh_ctx* c, const float* d_pcm, size_t n_clips, const wh_decode_params* p,
+                               int64_t* tokens_out, size_t* n_tokens_out);
+
+/* ---- long-form (src/main.rs:834-1008): whole-file mel once, 30 s windows every
+ * (chunk_len - overlap) samples, all windows decoded as batches; returns per-window tokens ------ */
+int wh_longform_plan(size_t n_samples, double chunk_length_s, double overlap_s, size_t* offsets, size_t cap,
+                     size_t* n_chunks); /* chunk start samples, src/main.rs:858-882 */
+int wh_transcribe_longform(wh_ctx* c, const float* pcm, size_t n_samples, double chunk_length_s, double overlap_s,
+                           const wh_decode_params* p, int64_t* tokens_out /* [n_chunks][n_prompt+max_new] */,
+                           size_t* n_tokens_out /* [n_chunks] */, size_t cap_chunks, size_t* n_chunks_out);
+
+/* ---- measurement hooks (bench.py): time named kernel groups with HIP events on the ctx stream -- */
+#define WH_KG_MEL 0
+#define WH_KG_ENC_GEMM 1
+#define WH_KG_ENC_ATTN 2
+#define WH_KG_DEC_CROSS_ATTN 3
+#define WH_KG_DEC_GEMM 4
+#define WH_KG_DEC_OTHER 5
+#define WH_KG_COUNT 6
+/* When enabled, every launch of the group is bracketed by hipEvents on the launch stream; the
+ * totals of the last transcribe call are returned as (milliseconds, launches) per group. */
+int wh_profile_enable(wh_ctx* c, int enable);
+int wh_profile_get(const wh_ctx* c, double* ms /* [WH_KG_COUNT] */, int64_t* launches /* [WH_KG_COUNT] */);
+
+int wh_abi_version(void);
+int wh_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WHISPER_HIP_H */

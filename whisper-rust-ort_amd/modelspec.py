@@ -1,0 +1,220 @@
+"""Model geometry, canonical tensor table and the hash-seeded synthetic weights.
+
+No Whisper checkpoint exists in this pipeline (reference `.gitignore:13-14` keeps the
+ONNX/weight directories out of the tree, and there is no network), so every run uses
+weights defined by an integer hash of (tensor name, seed, flat index).  The same
+definition is implemented in C++ inside the HIP library (`csrc/wh_weights.cpp`); the
+test-suite checks the two bit-for-bit.
+
+Tensor names follow the HF `WhisperForConditionalGeneration` state-dict
+(`model.encoder.conv1.weight`, `model.decoder.layers.N.encoder_attn.k_proj.weight`, ...),
+i.e. the layout of a real `model.safetensors`, which the library's loader also accepts.
+Those graphs are what the reference executes through ONNX Runtime
+(reference `src/main.rs:1099-1108`, exported by `scripts/export_onnx_whisper.py:19-28`).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, asdict
+from typing import Dict, Iterator, List, Tuple
+
+import numpy as np
+
+N_FRAMES = 3000  # 30 s window, hop 160 @16 kHz (reference src/main.rs:896-905)
+
+
+@dataclass(frozen=True)
+class WhisperDims:
+    n_mels: int
+    d_model: int
+    n_heads: int
+    enc_layers: int
+    dec_layers: int
+    ffn: int
+    vocab: int
+    n_audio_ctx: int = 1500
+    n_text_ctx: int = 448
+
+    @property
+    def head_dim(self) -> int:
+        return self.d_model // self.n_heads
+
+    def as_dict(self) -> dict:
+        return asdict(self)
+
+
+PRESETS: Dict[str, WhisperDims] = {
+    # small enough that the scalar C oracle finishes in well under a second
+    "nano": WhisperDims(n_mels=80, d_model=128, n_heads=2, enc_layers=2, dec_layers=2,
+                        ffn=256, vocab=1024),
+    # same shape family as base but ~10x cheaper: used for wider parity sweeps
+    "micro": WhisperDims(n_mels=80, d_model=256, n_heads=4, enc_layers=2, dec_layers=3,
+                         ffn=1024, vocab=4099),
+    # openai/whisper-base
+    "base": WhisperDims(n_mels=80, d_model=512, n_heads=8, enc_layers=6, dec_layers=6,
+                        ffn=2048, vocab=51865),
+    # openai/whisper-large-v3 (128 mel bins, vocab 51866)
+    "large-v3": WhisperDims(n_mels=128, d_model=1280, n_heads=20, enc_layers=32,
+                            dec_layers=32, ffn=5120, vocab=51866),
+}
+
+
+def tensor_table(dims: WhisperDims) -> List[Tuple[str, Tuple[int, ...]]]:
+    """Canonical (name, shape) list. The flat weight blob used by the oracle and the
+    library's internal arena both follow exactly this order."""
+    d, F = dims.d_model, dims.ffn
+    t: List[Tuple[str, Tuple[int, ...]]] = []
+
+    def attn(prefix: str) -> None:
+        t.append((f"{prefix}.q_proj.weight", (d, d)))
+        t.append((f"{prefix}.q_proj.bias", (d,)))
+        t.append((f"{prefix}.k_proj.weight", (d, d)))  # k_proj has no bias
+        t.append((f"{prefix}.v_proj.weight", (d, d)))
+        t.append((f"{prefix}.v_proj.bias", (d,)))
+        t.append((f"{prefix}.out_proj.weight", (d, d)))
+        t.append((f"{prefix}.out_proj.bias", (d,)))
+
+    def ln(prefix: str) -> None:
+        t.append((f"{prefix}.weight", (d,)))
+        t.append((f"{prefix}.bias", (d,)))
+
+    def mlp(prefix: str) -> None:
+        t.append((f"{prefix}.fc1.weight", (F, d)))
+        t.append((f"{prefix}.fc1.bias", (F,)))
+        t.append((f"{prefix}.fc2.weight", (d, F)))
+        t.append((f"{prefix}.fc2.bias", (d,)))
+
+    e = "model.encoder"
+    t.append((f"{e}.conv1.weight", (d, dims.n_mels, 3)))
+    t.append((f"{e}.conv1.bias", (d,)))
+    t.append((f"{e}.conv2.weight", (d, d, 3)))
+    t.append((f"{e}.conv2.bias", (d,)))
+    t.append((f"{e}.embed_positions.weight", (dims.n_audio_ctx, d)))
+    for i in range(dims.enc_layers):
+        p = f"{e}.layers.{i}"
+        attn(f"{p}.self_attn")
+        ln(f"{p}.self_attn_layer_norm")
+        mlp(p)
+        ln(f"{p}.final_layer_norm")
+    ln(f"{e}.layer_norm")
+
+    dd = "model.decoder"
+    t.append((f"{dd}.embed_tokens.weight", (dims.vocab, d)))
+    t.append((f"{dd}.embed_positions.weight", (dims.n_text_ctx, d)))
+    for i in range(dims.dec_layers):
+        p = f"{dd}.layers.{i}"
+        attn(f"{p}.self_attn")
+        ln(f"{p}.self_attn_layer_norm")
+        attn(f"{p}.encoder_attn")
+        ln(f"{p}.encoder_attn_layer_norm")
+        mlp(p)
+        ln(f"{p}.final_layer_norm")
+    ln(f"{dd}.layer_norm")
+    return t
+
+
+def n_params(dims: WhisperDims) -> int:
+    return sum(int(np.prod(s)) for _, s in tensor_table(dims))
+
+
+# ----------------------------------------------------------------------------------
+# hash-seeded values
+# ----------------------------------------------------------------------------------
+_GOLD = 0x9E3779B97F4A7C15
+_M64 = (1 << 64) - 1
+
+
+def fnv1a64(name: str) -> int:
+    h = 0xCBF29CE484222325
+    for b in name.encode("utf-8"):
+        h ^= b
+        h = (h * 0x100000001B3) & _M64
+    return h
+
+
+def _splitmix_u24(key: int, n: int) -> np.ndarray:
+    """24 uniform bits per flat index i: splitmix64 finaliser of key + i*GOLD."""
+    with np.errstate(over="ignore"):
+        i = np.arange(n, dtype=np.uint64)
+        z = np.uint64(key) + i * np.uint64(_GOLD)
+        z ^= z >> np.uint64(30)
+        z *= np.uint64(0xBF58476D1CE4E5B9)
+        z ^= z >> np.uint64(27)
+        z *= np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+        return (z >> np.uint64(40)).astype(np.uint32)
+
+
+def sinusoid_positions(length: int, channels: int) -> np.ndarray:
+    """[3P] transformers modeling_whisper.py `sinusoids` (:55-64): [sin | cos] halves,
+    timescale increment log(10000)/(channels/2 - 1).  Evaluated in float64, stored f32."""
+    half = channels // 2
+    inc = math.log(10000.0) / (half - 1)
+    inv = np.exp(-inc * np.arange(half, dtype=np.float64))
+    st = np.arange(length, dtype=np.float64)[:, None] * inv[None, :]
+    return np.concatenate([np.sin(st), np.cos(st)], axis=1).astype(np.float32)
+
+
+def value_rule(name: str, shape: Tuple[int, ...]) -> Tuple[float, float]:
+    """(offset, amplitude): value = offset + amplitude * U[-1,1)."""
+    if name.endswith("layer_norm.weight"):
+        return 1.0, 0.1
+    if name.endswith(".bias"):
+        return 0.0, 0.1
+    if name.endswith("embed_tokens.weight"):
+        return 0.0, 0.2
+    if name.endswith("decoder.embed_positions.weight"):
+        return 0.0, 0.05
+    fan_in = int(np.prod(shape[1:]))
+    return 0.0, float(np.float32(math.sqrt(3.0 / fan_in)))
+
+
+def synth_tensor(name: str, shape: Tuple[int, ...], seed: int) -> np.ndarray:
+    if name.endswith("encoder.embed_positions.weight"):
+        return sinusoid_positions(shape[0], shape[1])
+    n = int(np.prod(shape))
+    key = (fnv1a64(name) ^ ((seed * _GOLD) & _M64)) & _M64
+    u = _splitmix_u24(key, n)
+    off, amp = value_rule(name, shape)
+    # (u - 2^23) is exact in f32; one rounding in the multiply, one in the add
+    v = (u.astype(np.float32) - np.float32(8388608.0)) * (np.float32(amp) / np.float32(8388608.0))
+    if off != 0.0:
+        v = np.float32(off) + v
+    return v.astype(np.float32).reshape(shape)
+
+
+def synth_state_dict(dims: WhisperDims, seed: int) -> Dict[str, np.ndarray]:
+    return {n: synth_tensor(n, s, seed) for n, s in tensor_table(dims)}
+
+
+def flatten_state_dict(dims: WhisperDims, sd: Dict[str, np.ndarray]) -> np.ndarray:
+    """One contiguous f32 blob in `tensor_table` order (what `oracle/` consumes)."""
+    parts = []
+    for name, shape in tensor_table(dims):
+        a = np.ascontiguousarray(sd[name], dtype=np.float32)
+        assert tuple(a.shape) == tuple(shape), (name, a.shape, shape)
+        parts.append(a.reshape(-1))
+    return np.concatenate(parts)
+
+
+def iter_offsets(dims: WhisperDims) -> Iterator[Tuple[str, Tuple[int, ...], int]]:
+    off = 0
+    for name, shape in tensor_table(dims):
+        yield name, shape, off
+        off += int(np.prod(shape))
+
+
+# ----------------------------------------------------------------------------------
+# synthetic audio
+# ----------------------------------------------------------------------------------
+def synth_clip(index: int, base_seed: int = 1000, n: int = 480000) -> np.ndarray:
+    """Clip i: three enveloped sinusoids (80-4000 Hz) + N(0, 0.02^2) noise, 16 kHz mono,
+    clipped to [-1, 1].  Deterministic for a given numpy version's PCG64."""
+    rng = np.random.Generator(np.random.PCG64(base_seed + index))
+    t = np.arange(n, dtype=np.float64) / 16000.0
+    f = rng.uniform(80.0, 4000.0, size=3)
+    ph = rng.uniform(0.0, 2 * math.pi, size=3)
+    env = 0.5 - 0.5 * np.cos(2 * math.pi * 4.0 * t)
+    x = 0.25 * sum(np.sin(2 * math.pi * f[j] * t + ph[j]) for j in range(3)) * env
+    x = x + 0.02 * rng.standard_normal(n)
+    return np.clip(x, -1.0, 1.0).astype(np.float32)
