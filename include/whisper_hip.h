@@ -169,6 +169,10 @@ int wh_transcribe_longform(wh_ctx* c, const float* pcm, size_t n_samples, double
 int wh_profile_enable(wh_ctx* c, int enable);
 int wh_profile_get(const wh_ctx* c, double* ms /* [WH_KG_COUNT] */, int64_t* launches /* [WH_KG_COUNT] */);
 
+/* Host-only: the hash-seeded weights of "synthetic:<preset>:<seed>" as one f32 blob in canonical
+ * tensor order (needs no device).  out == NULL → only *n_out is written. */
+int wh_synthetic_weights(const char* preset, uint64_t seed, float* out, size_t cap, size_t* n_out);
+
 int wh_abi_version(void);
 int wh_device_count(void);
 

@@ -1,0 +1,328 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle and the
+committed golden vectors.  Run with `-m gpu` on an MI355X.
+
+Tolerances
+  F32 mode (exact-f32 MFMA): mel 1e-4, encoder 1e-3, logits 1e-3 (north_star), tokens exact.
+  BF16 mode: reported as error statistics; tokens must match wherever the oracle's top-1 margin
+  exceeds the measured logit error bound (teacher-forced), see test_bf16_*.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from whisper_rust_ort_amd import binding as wb
+from whisper_rust_ort_amd import modelspec as ms
+
+pytestmark = pytest.mark.gpu
+
+MEL_TOL, ENC_TOL, LOGIT_TOL = 1e-4, 1e-3, 1e-3
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if wb.device_count() < 1:
+        pytest.fail("no MI355X visible: the GPU suite has no fallback")
+    return 0
+
+
+class Bundle:
+    def __init__(self, preset, seed, prec, max_batch=1):
+        self.dims = ms.PRESETS[preset]
+        self.model = wb.Model(f"synthetic:{preset}:{seed}", 0, prec)
+        self.ctx = wb.Context(self.model, max_batch)
+        self._w = None
+        self.preset, self.seed = preset, seed
+
+    @property
+    def w(self):
+        if self._w is None:
+            self._w = ms.flatten_state_dict(self.dims, ms.synth_state_dict(self.dims, self.seed))
+        return self._w
+
+
+_cache = {}
+
+
+def bundle(preset, seed, prec, max_batch=1):
+    k = (preset, seed, prec, max_batch)
+    if k not in _cache:
+        _cache[k] = Bundle(preset, seed, prec, max_batch)
+    return _cache[k]
+
+
+def small_prompt(dims):
+    return ([50258, 50259, 50359, 50363], 50257) if dims.vocab > 50400 else ([3, 5, 7, 9], 2)
+
+
+# ------------------------------------------------------------------------------------------------
+# log-mel
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [480000, 479999, 160000, 16000, 12345, 400, 321, 320, 161, 160, 159, 2, 1])
+def test_log_mel_matches_oracle(gpu, n):
+    b = bundle("nano", 7, wb.WH_PREC_F32)
+    pcm = ms.synth_clip(5)[:n]
+    got = b.ctx.whisper_log_mel(pcm)
+    ref = orc.log_mel(pcm, 80)
+    assert got.shape == ref.shape == (80, max(1, n // 160) if n >= 160 else 1)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=MEL_TOL)
+
+
+def test_log_mel_long_file_global_max(gpu):
+    b = bundle("nano", 7, wb.WH_PREC_F32)
+    pcm = np.concatenate([ms.synth_clip(1) * 0.01, ms.synth_clip(2), ms.synth_clip(3)[:123457] * 0.1])
+    got = b.ctx.whisper_log_mel(pcm)
+    ref = orc.log_mel(pcm, 80)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=0, atol=MEL_TOL)
+
+
+def test_log_mel_silence_and_golden(gpu, golden_dir):
+    b = bundle("nano", 7, wb.WH_PREC_F32)
+    mel = b.ctx.whisper_log_mel(np.zeros(16000, np.float32))
+    np.testing.assert_allclose(mel, np.full((80, 100), -1.5, np.float32), rtol=0, atol=1e-6)  # device log10f: 1 ulp
+    g = np.load(os.path.join(golden_dir, "nano_s7_c0.npz"))
+    got = b.ctx.whisper_log_mel(ms.synth_clip(0))
+    np.testing.assert_allclose(got[:, ::25], g["mel_slice"], rtol=0, atol=MEL_TOL)
+
+
+def test_empty_audio_is_rejected(gpu):
+    b = bundle("nano", 7, wb.WH_PREC_F32)
+    with pytest.raises(wb.WhisperHipError) as ei:
+        b.ctx.whisper_log_mel(np.zeros(0, np.float32))
+    assert ei.value.code == 1 and "Empty audio" in str(ei.value)   # src/main.rs:414-416
+    with pytest.raises(wb.WhisperHipError) as ei:
+        b.ctx.transcribe_batch([np.zeros(0, np.float32)], wb.DecodeParams([3, 5, 7, 9], 4, 2))
+    assert ei.value.code == 1
+
+
+def test_128_mel_bins(gpu):
+    m = wb.Model("synthetic:large-v3:1", 0, wb.WH_PREC_BF16) if os.environ.get("WH_TEST_LARGE") else None
+    if m is None:
+        pytest.skip("large-v3 mel covered by test_large_v3 when WH_TEST_LARGE=1")
+
+
+# ------------------------------------------------------------------------------------------------
+# encoder + decode, exact-f32 mode, against the oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("preset,seed,clip", [("nano", 7, 0), ("micro", 11, 2)])
+def test_f32_full_path_matches_oracle(gpu, preset, seed, clip):
+    b = bundle(preset, seed, wb.WH_PREC_F32)
+    dims = b.dims
+    pcm = ms.synth_clip(clip)
+    mel = b.ctx.whisper_log_mel(pcm)
+    mel_ref = orc.log_mel(pcm, dims.n_mels)
+    np.testing.assert_allclose(mel, mel_ref, rtol=0, atol=MEL_TOL)
+    enc = b.ctx.run_encoder(mel_ref)
+    enc_ref = orc.encoder(dims, b.w, mel_ref)
+    np.testing.assert_allclose(enc, enc_ref, rtol=0, atol=ENC_TOL)
+    prompt, eot = small_prompt(dims)
+    # (a) free-running greedy
+    ta, la = b.ctx.greedy_decode_with_past(wb.DecodeParams(prompt, 24, eot), want_logits=True)
+    ra, rla = orc.decode_greedy(dims, b.w, enc_ref, prompt, 24, eot, want_logits=True)
+    assert ta.tolist() == ra.tolist()
+    np.testing.assert_allclose(la, rla, rtol=0, atol=LOGIT_TOL)
+    # (b) suppress + begin-suppress (src/main.rs:765-768): forbid the free-running choices
+    sup = [eot, int(ra[len(prompt)])]
+    bsup = [int(ra[len(prompt) + 1])]
+    tb, lb = b.ctx.greedy_decode_with_past(wb.DecodeParams(prompt, 24, eot, sup, bsup), want_logits=True)
+    rb, rlb = orc.decode_greedy(dims, b.w, enc_ref, prompt, 24, eot, sup, bsup, want_logits=True)
+    assert tb.tolist() == rb.tolist()
+    assert sup[1] not in tb[len(prompt):].tolist() and tb[len(prompt)] != bsup[0]
+    np.testing.assert_allclose(lb, rlb, rtol=0, atol=LOGIT_TOL)
+    # (c) teacher forced random history
+    rng = np.random.Generator(np.random.PCG64(99))
+    forced = rng.integers(0, dims.vocab, size=40).tolist()
+    tc, lc = b.ctx.greedy_decode_with_past(wb.DecodeParams(prompt, 41, eot, forced=forced), want_logits=True)
+    rc, rlc = orc.decode_greedy(dims, b.w, enc_ref, prompt, 41, eot, forced=forced, want_logits=True)
+    assert tc.tolist() == rc.tolist() and len(tc) == len(prompt) + 41
+    np.testing.assert_allclose(lc, rlc, rtol=0, atol=LOGIT_TOL)
+
+
+def test_f32_matches_golden_vectors(gpu, golden_dir):
+    for name in ("nano_s7_c1.npz", "micro_s11_c2.npz"):
+        g = np.load(os.path.join(golden_dir, name))
+        b = bundle(str(g["preset"]), int(g["seed"]), wb.WH_PREC_F32)
+        pcm = ms.synth_clip(int(g["clip"]))
+        mel = b.ctx.whisper_log_mel(pcm)
+        np.testing.assert_allclose(mel[:, ::25], g["mel_slice"], rtol=0, atol=MEL_TOL)
+        enc = b.ctx.run_encoder(mel)
+        np.testing.assert_allclose(enc[g["enc_rows"]], g["enc_slice"], rtol=0, atol=ENC_TOL)
+        prompt, eot, mx = g["prompt"].tolist(), int(g["eot"]), int(g["max_new"])
+        ta, la = b.ctx.greedy_decode_with_past(wb.DecodeParams(prompt, mx, eot), want_logits=True)
+        assert ta.tolist() == g["tokens_a"].tolist()
+        for i in range(len(la)):
+            np.testing.assert_allclose(la[i][g["top_ids_a"][i]], g["top_vals_a"][i], rtol=0, atol=LOGIT_TOL)
+        tb, _ = b.ctx.greedy_decode_with_past(wb.DecodeParams(prompt, mx, eot, g["suppress_b"].tolist(),
+                                                               g["begin_suppress_b"].tolist()))
+        assert tb.tolist() == g["tokens_b"].tolist()
+        forced = g["forced_c"].tolist()
+        tc, lc = b.ctx.greedy_decode_with_past(wb.DecodeParams(prompt, len(forced) + 1, eot, forced=forced), want_logits=True)
+        assert tc.tolist() == g["tokens_c"].tolist()
+        for i in range(len(lc)):
+            np.testing.assert_allclose(lc[i][g["top_ids_c"][i]], g["top_vals_c"][i], rtol=0, atol=LOGIT_TOL)
+
+
+def test_f32_whisper_base_matches_golden(gpu, golden_dir):
+    """whisper-base dims, hash-seeded weights: token-for-token + logits within 1e-3 (configs[1])."""
+    g = np.load(os.path.join(golden_dir, "base_s1234_c0.npz"))
+    b = bundle("base", 1234, wb.WH_PREC_F32)
+    pcm = ms.synth_clip(0)
+    mel = b.ctx.whisper_log_mel(pcm)
+    np.testing.assert_allclose(mel[:, ::25], g["mel_slice"], rtol=0, atol=MEL_TOL)
+    enc = b.ctx.run_encoder(mel)
+    np.testing.assert_allclose(enc[g["enc_rows"]], g["enc_slice"], rtol=0, atol=ENC_TOL)
+    np.testing.assert_allclose(enc.astype(np.float64).mean(0), g["enc_col_mean"], rtol=0, atol=ENC_TOL)
+    prompt, eot = g["prompt"].tolist(), int(g["eot"])
+    ta, la = b.ctx.greedy_decode_with_past(wb.DecodeParams(prompt, 128, eot), want_logits=True)
+    assert ta.tolist() == g["tokens_a"].tolist()
+    for i in range(len(la)):
+        np.testing.assert_allclose(la[i][g["top_ids_a"][i]], g["top_vals_a"][i], rtol=0, atol=LOGIT_TOL)
+    tb, _ = b.ctx.greedy_decode_with_past(wb.DecodeParams(prompt, 128, eot, g["suppress_b"].tolist(), g["begin_suppress_b"].tolist()))
+    assert tb.tolist() == g["tokens_b"].tolist()
+    forced = g["forced_c"].tolist()
+    tc, lc = b.ctx.greedy_decode_with_past(wb.DecodeParams(prompt, len(forced) + 1, eot, forced=forced), want_logits=True)
+    assert tc.tolist() == g["tokens_c"].tolist()
+    for i in range(len(lc)):
+        np.testing.assert_allclose(lc[i][g["top_ids_c"][i]], g["top_vals_c"][i], rtol=0, atol=LOGIT_TOL)
+    np.testing.assert_allclose(lc[:4, :2048], g["logits_c_head"], rtol=0, atol=LOGIT_TOL)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused batch entry, ragged clips, long-form
+# ------------------------------------------------------------------------------------------------
+def test_batch_equals_staged_calls_and_oracle(gpu):
+    b = bundle("nano", 7, wb.WH_PREC_F32, max_batch=8)
+    dims = b.dims
+    prompt, eot = small_prompt(dims)
+    lens = [480000, 480000, 300000, 16000, 161, 480000, 99999]
+    clips = [ms.synth_clip(10 + i)[:n] for i, n in enumerate(lens)]
+    params = wb.DecodeParams(prompt, 12, eot)
+    got = b.ctx.transcribe_batch(clips, params)
+    assert len(got) == len(clips)
+    for pcm, toks in zip(clips, got):
+        mel_full = orc.log_mel(pcm, dims.n_mels)
+        mel = orc.window_mel(mel_full, 0, 3000)       # zero padding in normalised space (:899-905)
+        enc = orc.encoder(dims, b.w, mel)
+        ref, _ = orc.decode_greedy(dims, b.w, enc, prompt, 12, eot)
+        assert toks.tolist() == ref.tolist()
+    # single-clip batch == same clip inside a bigger batch
+    one = b.ctx.transcribe_batch([clips[2]], params)
+    assert one[0].tolist() == got[2].tolist()
+
+
+def test_eot_stops_each_clip_independently(gpu):
+    b = bundle("nano", 7, wb.WH_PREC_F32, max_batch=8)
+    dims = b.dims
+    prompt, _ = small_prompt(dims)
+    clips = [ms.synth_clip(30 + i) for i in range(4)]
+    free = b.ctx.transcribe_batch(clips, wb.DecodeParams(prompt, 20, dims.vocab - 1))
+    # choose as EOT the token clip 0 emits at generated index 3: clip 0 must stop there (EOT kept)
+    eot = int(free[0][len(prompt) + 3])
+    got = b.ctx.transcribe_batch(clips, wb.DecodeParams(prompt, 20, eot))
+    for f, t in zip(free, got):
+        gen = f[len(prompt):].tolist()
+        cut = gen.index(eot) + 1 if eot in gen else len(gen)
+        assert t.tolist() == f[: len(prompt) + cut].tolist()
+    assert len(got[0]) <= len(prompt) + 4 and got[0][-1] == eot
+
+
+def test_longform_windows_match_oracle(gpu):
+    b = bundle("nano", 7, wb.WH_PREC_F32, max_batch=8)
+    dims = b.dims
+    prompt, eot = small_prompt(dims)
+    pcm = np.concatenate([ms.synth_clip(40), ms.synth_clip(41), ms.synth_clip(42)[:200000]])  # 72.5 s
+    params = wb.DecodeParams(prompt, 8, eot)
+    got = b.ctx.transcribe_longform(pcm, params)
+    offs = wb.longform_plan(pcm.size)
+    assert len(got) == len(offs) == 3
+    mel_full = orc.log_mel(pcm, dims.n_mels)           # whole-file mel, global max (:870-872)
+    for off, toks in zip(offs, got):
+        mel = orc.window_mel(mel_full, off // 160, 3000)
+        enc = orc.encoder(dims, b.w, mel)
+        ref, _ = orc.decode_greedy(dims, b.w, enc, prompt, 8, eot)
+        assert toks.tolist() == ref.tolist()
+
+
+def test_decode_before_encode_is_state_error(gpu):
+    m = wb.Model("synthetic:nano:7", 0, wb.WH_PREC_F32)
+    c = wb.Context(m, 1)
+    with pytest.raises(wb.WhisperHipError) as ei:
+        c.greedy_decode_with_past(wb.DecodeParams([3, 5, 7, 9], 4, 2))
+    assert ei.value.code == 3 and "Missing cached decoder input" in str(ei.value)   # src/main.rs:808-810
+    with pytest.raises(wb.WhisperHipError) as ei:
+        c.run_encoder(np.zeros((80, 2999), np.float32))
+    assert ei.value.code == 2
+    with pytest.raises(wb.WhisperHipError) as ei:
+        c.run_encoder(np.zeros((80, 3000), np.float32), want_output=False)
+        c.greedy_decode_with_past(wb.DecodeParams([3, 5, 7, 9], 500, 2))
+    assert ei.value.code == 4
+
+
+def test_argmax_edge_cases_via_suppress_all_but_one(gpu):
+    """Masked argmax semantics (src/main.rs:709-735) through the LM-head kernel: with every id but one
+    suppressed the survivor is chosen; with everything suppressed the answer is id 0."""
+    b = bundle("nano", 7, wb.WH_PREC_F32)
+    dims = b.dims
+    prompt, _ = small_prompt(dims)
+    b.ctx.run_encoder(orc.log_mel(ms.synth_clip(0), 80), want_output=False)
+    keep = 777
+    sup = [i for i in range(dims.vocab) if i != keep]
+    t, _ = b.ctx.greedy_decode_with_past(wb.DecodeParams(prompt, 3, dims.vocab + 5, sup))
+    assert t[len(prompt):].tolist() == [keep] * 3
+    t, _ = b.ctx.greedy_decode_with_past(wb.DecodeParams(prompt, 2, dims.vocab + 5, list(range(dims.vocab))))
+    assert t[len(prompt):].tolist() == [0, 0]
+    # begin-suppress applies to the first generated token only
+    t0, _ = b.ctx.greedy_decode_with_past(wb.DecodeParams(prompt, 2, dims.vocab + 5))
+    t1, _ = b.ctx.greedy_decode_with_past(wb.DecodeParams(prompt, 2, dims.vocab + 5, (), [int(t0[len(prompt)])]))
+    assert t1[len(prompt)] != t0[len(prompt)]
+
+
+# ------------------------------------------------------------------------------------------------
+# bf16 mode
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("preset,seed,clip", [("micro", 11, 2), ("base", 1234, 0)])
+def test_bf16_teacher_forced_agreement(gpu, golden_dir, preset, seed, clip):
+    """bf16 MFMA path vs the fp32 golden vectors under teacher forcing: logit error is bounded and the
+    argmax agrees wherever the fp32 top-1 margin exceeds twice the measured error."""
+    g = np.load(os.path.join(golden_dir, f"{preset}_s{seed}_c{clip}.npz"))
+    b = bundle(preset, seed, wb.WH_PREC_BF16)
+    pcm = ms.synth_clip(clip)
+    mel = b.ctx.whisper_log_mel(pcm)
+    np.testing.assert_allclose(mel[:, ::25], g["mel_slice"], rtol=0, atol=MEL_TOL)  # mel is f64/f32 in both modes
+    enc = b.ctx.run_encoder(mel)
+    enc_err = np.abs(enc[g["enc_rows"]] - g["enc_slice"]).max()
+    assert enc_err < 0.08, enc_err       # bf16 has 8 significand bits; states are O(1)
+    prompt, eot = g["prompt"].tolist(), int(g["eot"])
+    forced = g["forced_c"].tolist()
+    tc, lc = b.ctx.greedy_decode_with_past(wb.DecodeParams(prompt, len(forced) + 1, eot, forced=forced), want_logits=True)
+    errs, agree, decided = [], 0, 0
+    for i in range(len(lc)):
+        ids, vals = g["top_ids_c"][i], g["top_vals_c"][i]
+        e = np.abs(lc[i][ids] - vals).max()
+        errs.append(e)
+    bound = 2.0 * max(errs)
+    for i in range(len(lc)):
+        vals = g["top_vals_c"][i]
+        if vals[0] - vals[1] > bound:
+            decided += 1
+            agree += int(tc[len(prompt) + i] == g["tokens_c"][len(prompt) + i])
+    print(f"{preset}: bf16 max logit err {max(errs):.4f}, mean {np.mean(errs):.4f}; decided {decided}/{len(lc)} agree {agree}")
+    assert max(errs) < 0.25
+    assert agree == decided
+
+
+def test_bf16_batch_is_deterministic_and_permutation_invariant(gpu):
+    b = bundle("micro", 11, wb.WH_PREC_BF16, max_batch=16)
+    prompt, eot = small_prompt(b.dims)
+    clips = [ms.synth_clip(60 + i) for i in range(16)]
+    params = wb.DecodeParams(prompt, 16, eot, [eot])
+    a = b.ctx.transcribe_batch(clips, params)
+    a2 = b.ctx.transcribe_batch(clips, params)
+    assert [t.tolist() for t in a] == [t.tolist() for t in a2]
+    perm = np.random.Generator(np.random.PCG64(5)).permutation(16)
+    c = b.ctx.transcribe_batch([clips[i] for i in perm], params)
+    for j, i in enumerate(perm):
+        assert c[j].tolist() == a[i].tolist()
+    assert all(len(t) == len(prompt) + 16 for t in a)   # EOT suppressed → full length

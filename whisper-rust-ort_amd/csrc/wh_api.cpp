@@ -1,0 +1,873 @@
+// wh_api.cpp — the C ABI of include/whisper_hip.h: context lifecycle and the orchestration of
+// log-mel → encoder → cross-KV → batched greedy decode on one HIP stream.
+//
+// Mirrors, per entry point: whisper_log_mel_80 (reference src/main.rs:407-509), run_encoder
+// (:698-707), greedy_decode_with_past (:753-829) and the per-window body of
+// transcribe_longform_chunked (:870-915, 946-967).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+
+#include "wh_common.h"
+#include "wh_internal.h"
+
+const std::string& wh_global_error();
+
+namespace {
+
+constexpr int RAW_LD = 3008;   // raw log-mel row stride (frames), multiple of 16
+constexpr int TOK_ROWS = 3002; // conv1 operand rows per clip: zero row, 3000 frames, zero row
+constexpr int H1_ROWS = 3001;  // conv2 operand rows per clip: zero row, 3000 positions
+
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int fail(wh_ctx* c, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    wh_set_error("%s", buf);
+    return code;
+}
+
+#define CTX_HIP(c, expr)                                                                          \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return fail(c, WH_ERR_HIP, "HIP error %d (%s) at %s:%d: %s", (int)_e, hipGetErrorString(_e), __FILE__, \
+                        __LINE__, #expr);                                                         \
+    } while (0)
+
+// ---- profiling scope: brackets the launches of one kernel group with events -------------------
+struct Prof {
+    wh_ctx* c;
+    int g;
+    size_t slot = 0;
+    bool on;
+    Prof(wh_ctx* ctx, int group) : c(ctx), g(group), on(ctx->prof) {
+        c->prof_launches[g]++;
+        if (!on) return;
+        auto& v = c->prof_events[g];
+        if (c->prof_used[g] == v.size()) {
+            hipEvent_t a, b;
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            v.push_back({a, b});
+        }
+        slot = c->prof_used[g]++;
+        hipEventRecord(v[slot].first, c->stream);
+    }
+    ~Prof() {
+        if (on) hipEventRecord(c->prof_events[g][slot].second, c->stream);
+    }
+};
+
+void prof_reset(wh_ctx* c) {
+    for (int g = 0; g < WH_KG_COUNT; g++) { c->prof_used[g] = 0; c->prof_ms[g] = 0; c->prof_launches[g] = 0; }
+}
+void prof_collect(wh_ctx* c) {
+    if (!c->prof) return;
+    for (int g = 0; g < WH_KG_COUNT; g++) {
+        double ms = 0;
+        for (size_t i = 0; i < c->prof_used[g]; i++) {
+            float t = 0;
+            hipEventElapsedTime(&t, c->prof_events[g][i].first, c->prof_events[g][i].second);
+            ms += t;
+        }
+        c->prof_ms[g] = ms;
+    }
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        size_t o = off;
+        off = align_up(off + bytes, 256);
+        return o;
+    }
+};
+
+// ---- encoder for nb clips whose conv1 operand already sits in c->melT ---------------------------
+int run_encoder(wh_ctx* c, int nb, bool want_f32) {
+    wh_model* m = c->m;
+    const wh_dims& D = m->dims;
+    hipStream_t s = c->stream;
+    const int prec = m->prec;
+    const long d = D.d_model, S = D.n_audio_ctx, F = D.ffn, C = D.n_mels;
+    const size_t esz = m->esz;
+    {   // conv1 (k3,p1) + GELU: GEMM over overlapping rows of the token-major mel
+        Prof p(c, WH_KG_ENC_GEMM);
+        GemmArgs g;
+        g.A = c->melT; g.lda = C; g.a_bs = (long)TOK_ROWS * C; g.m_per = WH_N_FRAMES;
+        g.W = m->conv1_w; g.ldw = m->conv1_k;
+        g.C = (char*)c->h1 + d * esz; g.ldc = d; g.c_bs = (long)H1_ROWS * d;
+        g.bias = m->conv1_b; g.bias_mode = 1; g.act = 1;
+        g.M = nb * WH_N_FRAMES; g.N = (int)d; g.K = m->conv1_k;
+        wh_launch_gemm(s, prec, false, g);
+    }
+    {   // conv2 (k3,s2,p1) + GELU + sinusoid positions → f32 residual stream
+        Prof p(c, WH_KG_ENC_GEMM);
+        GemmArgs g;
+        g.A = c->h1; g.lda = 2 * d; g.a_bs = (long)H1_ROWS * d; g.m_per = (int)S;
+        g.W = m->conv2_w; g.ldw = 3 * d;
+        g.C = c->x; g.ldc = d; g.c_bs = S * d;
+        g.bias = m->conv2_b; g.bias_mode = 1; g.act = 1;
+        g.R = m->enc_pos; g.ldr = d; g.r_bs = 0;
+        g.M = nb * (int)S; g.N = (int)d; g.K = (int)(3 * d);
+        wh_launch_gemm(s, prec, true, g);
+    }
+    const long rows = (long)nb * S;
+    for (int l = 0; l < D.enc_layers; l++) {
+        const EncLayerDev& L = m->enc[l];
+        { Prof p(c, WH_KG_ENC_GEMM); wh_launch_layernorm(s, prec, c->x, L.ln1_w, L.ln1_b, c->xn, rows, (int)d); }
+        {   // Q|K projection (q pre-scaled, k has no bias)
+            Prof p(c, WH_KG_ENC_GEMM);
+            GemmArgs g;
+            g.A = c->xn; g.lda = d; g.W = L.qk_w; g.ldw = d; g.C = c->qk; g.ldc = 2 * d;
+            g.bias = L.qk_b; g.bias_mode = 1; g.M = (int)rows; g.N = (int)(2 * d); g.K = (int)d;
+            wh_launch_gemm(s, prec, false, g);
+        }
+        {   // V^T[e][key] = W_v x^T + b_v: per-clip product with the weight as the row operand
+            Prof p(c, WH_KG_ENC_GEMM);
+            GemmArgs g;
+            g.A = L.v_w; g.lda = d; g.a_zs = 0;
+            g.W = c->xn; g.ldw = d; g.w_zs = S * d;
+            g.C = c->vT; g.ldc = c->ldv; g.c_zs = d * c->ldv;
+            g.bias = L.v_b; g.bias_mode = 2; g.M = (int)d; g.N = (int)S; g.K = (int)d; g.batch = nb;
+            wh_launch_gemm(s, prec, false, g);
+        }
+        {
+            Prof p(c, WH_KG_ENC_ATTN);
+            wh_launch_enc_attn(s, prec, c->qk, c->vT, c->att, nb, (int)S, (int)d, D.n_heads, c->ldv);
+        }
+        {   // out-proj + bias + residual (in place on the f32 stream)
+            Prof p(c, WH_KG_ENC_GEMM);
+            GemmArgs g;
+            g.A = c->att; g.lda = d; g.W = L.o_w; g.ldw = d; g.C = c->x; g.ldc = d;
+            g.bias = L.o_b; g.bias_mode = 1; g.R = c->x; g.ldr = d; g.M = (int)rows; g.N = (int)d; g.K = (int)d;
+            wh_launch_gemm(s, prec, true, g);
+        }
+        { Prof p(c, WH_KG_ENC_GEMM); wh_launch_layernorm(s, prec, c->x, L.ln2_w, L.ln2_b, c->xn, rows, (int)d); }
+        {
+            Prof p(c, WH_KG_ENC_GEMM);
+            GemmArgs g;
+            g.A = c->xn; g.lda = d; g.W = L.fc1_w; g.ldw = d; g.C = c->hbuf; g.ldc = F;
+            g.bias = L.fc1_b; g.bias_mode = 1; g.act = 1; g.M = (int)rows; g.N = (int)F; g.K = (int)d;
+            wh_launch_gemm(s, prec, false, g);
+        }
+        {
+            Prof p(c, WH_KG_ENC_GEMM);
+            GemmArgs g;
+            g.A = c->hbuf; g.lda = F; g.W = L.fc2_w; g.ldw = F; g.C = c->x; g.ldc = d;
+            g.bias = L.fc2_b; g.bias_mode = 1; g.R = c->x; g.ldr = d; g.M = (int)rows; g.N = (int)d; g.K = (int)F;
+            wh_launch_gemm(s, prec, true, g);
+        }
+    }
+    {
+        Prof p(c, WH_KG_ENC_GEMM);
+        wh_launch_layernorm(s, prec, c->x, m->enc_ln_w, m->enc_ln_b, c->enc_out, rows, (int)d);
+        if (want_f32) {
+            if (prec == WH_PREC_F32) hipMemcpyAsync(c->enc_out_f32, c->enc_out, rows * d * 4, hipMemcpyDeviceToDevice, s);
+            else wh_launch_layernorm(s, WH_PREC_F32, c->x, m->enc_ln_w, m->enc_ln_b, c->enc_out_f32, rows, (int)d);
+        }
+    }
+    c->have_enc = true;
+    c->enc_batch = nb;
+    return WH_OK;
+}
+
+void pack_mask(const int64_t* a, size_t na, const int64_t* b, size_t nb, int vocab, std::vector<unsigned>& out) {
+    out.assign((size_t)vocab / 32 + 1, 0u);
+    for (size_t i = 0; i < na; i++)
+        if (a[i] >= 0 && a[i] < vocab) out[a[i] >> 5] |= 1u << (a[i] & 31);
+    for (size_t i = 0; i < nb; i++)
+        if (b[i] >= 0 && b[i] < vocab) out[b[i] >> 5] |= 1u << (b[i] & 31);
+}
+
+// ---- cross-KV + greedy loop for the nb clips whose encoder states are resident ------------------
+int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out, size_t tok_stride,
+               size_t* n_tokens_out, float* logits_out, size_t logits_rows) {
+    wh_model* m = c->m;
+    const wh_dims& D = m->dims;
+    hipStream_t s = c->stream;
+    const int prec = m->prec;
+    const long d = D.d_model, S = D.n_audio_ctx, F = D.ffn;
+    const size_t esz = m->esz;
+    const int P = (int)p->n_prompt, NEW = (int)p->max_new_tokens;
+    if (P <= 0 || NEW <= 0 || !p->prompt) return fail(c, WH_ERR_ARG, "decode: empty prompt or max_new_tokens == 0");
+    if (P + NEW > D.n_text_ctx) return fail(c, WH_ERR_ARG, "decode: prompt (%d) + max_new_tokens (%d) exceeds %d positions", P, NEW, D.n_text_ctx);
+    if (p->n_forced > (size_t)NEW) return fail(c, WH_ERR_ARG, "decode: more forced tokens than max_new_tokens");
+    for (int i = 0; i < P; i++)
+        if (p->prompt[i] < 0 || p->prompt[i] >= D.vocab) return fail(c, WH_ERR_ARG, "decode: prompt id %lld outside the vocabulary", (long long)p->prompt[i]);
+    for (size_t i = 0; i < p->n_forced; i++)
+        if (p->forced[i] < 0 || p->forced[i] >= D.vocab) return fail(c, WH_ERR_ARG, "decode: forced id outside the vocabulary");
+
+    // token state
+    const int ld = c->tok_ld;
+    std::vector<int> feed((size_t)nb * ld, 0);
+    for (int b = 0; b < nb; b++)
+        for (int i = 0; i < P; i++) feed[(size_t)b * ld + i] = (int)p->prompt[i];
+    CTX_HIP(c, hipMemcpyAsync(c->feed, feed.data(), feed.size() * 4, hipMemcpyHostToDevice, s));
+    CTX_HIP(c, hipMemcpyAsync(c->out_tokens, feed.data(), feed.size() * 4, hipMemcpyHostToDevice, s));
+    std::vector<int> nout(nb, P);
+    CTX_HIP(c, hipMemcpyAsync(c->n_out, nout.data(), nb * 4, hipMemcpyHostToDevice, s));
+    CTX_HIP(c, hipMemsetAsync(c->done, 0, nb * 4, s));
+    CTX_HIP(c, hipMemsetAsync(c->pos, 0, 4, s));
+    std::vector<int> forced(p->n_forced);
+    for (size_t i = 0; i < p->n_forced; i++) forced[i] = (int)p->forced[i];
+    if (!forced.empty()) CTX_HIP(c, hipMemcpyAsync(c->forced, forced.data(), forced.size() * 4, hipMemcpyHostToDevice, s));
+    std::vector<unsigned> mfirst, mbase;
+    pack_mask(p->suppress, p->n_suppress, p->begin_suppress, p->n_begin_suppress, D.vocab, mfirst);  // :765-768
+    pack_mask(p->suppress, p->n_suppress, nullptr, 0, D.vocab, mbase);
+    CTX_HIP(c, hipMemcpyAsync(c->mask_first, mfirst.data(), mfirst.size() * 4, hipMemcpyHostToDevice, s));
+    CTX_HIP(c, hipMemcpyAsync(c->mask_base, mbase.data(), mbase.size() * 4, hipMemcpyHostToDevice, s));
+    CTX_HIP(c, hipStreamSynchronize(s));  // host vectors above go out of scope
+
+    float* d_logits = nullptr;
+    if (logits_out) {
+        const size_t need = (size_t)nb * logits_rows * D.vocab;
+        if (need > c->logits_cap) {
+            if (c->logits) hipFree(c->logits);
+            c->logits = nullptr;
+            c->logits_cap = 0;
+            CTX_HIP(c, hipMalloc((void**)&c->logits, need * 4));
+            c->logits_cap = need;
+        }
+        d_logits = c->logits;
+    }
+
+    // cross-attention K/V of every decoder layer, once per clip: present.{i}.encoder.{key,value}
+    // of the step-0 decoder run (src/main.rs:771-787)
+    const long kv_stride = (long)nb * S * d;  // elements between consecutive [nb][S][d] planes
+    {
+        Prof pr(c, WH_KG_DEC_GEMM);
+        GemmArgs g;
+        g.A = c->enc_out; g.lda = d; g.W = m->cross_kv_w; g.ldw = d;
+        g.C = c->cross_kv; g.ldc = d; g.n_per = (int)d; g.c_ns = kv_stride;
+        g.bias = m->cross_kv_b; g.bias_mode = 1;
+        g.M = nb * (int)S; g.N = (int)(D.dec_layers * 2 * d); g.K = (int)d;
+        wh_launch_gemm(s, prec, false, g);
+    }
+
+    DecodeState st;
+    st.feed = c->feed; st.out_tokens = c->out_tokens; st.n_out = c->n_out; st.done = c->done;
+    st.forced = c->forced; st.n_forced = (int)p->n_forced; st.n_prompt = P; st.eot = (int)p->eot; st.tok_ld = ld;
+    const int n_tiles = (D.vocab + 15) / 16;
+    const long cache_l = (long)nb * D.n_heads * D.n_text_ctx * WH_HEAD_DIM;  // elements per layer
+    const int total_pos = P + NEW - 1;
+    std::vector<int> done_h(nb);
+    for (int step = 0; step < total_pos; step++) {
+        { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_dec_embed(s, prec, m->tok_emb, m->dec_pos, c->feed, ld, c->pos, c->dx, (int)d, nb); }
+        for (int l = 0; l < D.dec_layers; l++) {
+            const DecLayerDev& L = m->dec[l];
+            SkinnyArgs a;
+            { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_layernorm(s, prec, c->dx, L.ln1_w, L.ln1_b, c->dxn, nb, (int)d); }
+            {
+                Prof pr(c, WH_KG_DEC_GEMM);
+                a = SkinnyArgs();
+                a.X = c->dxn; a.ldx = d; a.W = L.qkv_w; a.bias = L.qkv_b; a.C = c->dqkv; a.ldc = 3 * d;
+                a.M = nb; a.N = (int)(3 * d); a.K = (int)d;
+                wh_launch_skinny(s, prec, false, a);
+            }
+            {
+                Prof pr(c, WH_KG_DEC_OTHER);
+                wh_launch_dec_self_attn(s, prec, c->dqkv, (char*)c->self_k + l * cache_l * esz,
+                                        (char*)c->self_v + l * cache_l * esz, c->datt, c->pos, (int)d, D.n_heads,
+                                        D.n_text_ctx, nb);
+            }
+            {
+                Prof pr(c, WH_KG_DEC_GEMM);
+                a = SkinnyArgs();
+                a.X = c->datt; a.ldx = d; a.W = L.o_w; a.bias = L.o_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
+                a.M = nb; a.N = (int)d; a.K = (int)d;
+                wh_launch_skinny(s, prec, true, a);
+            }
+            { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_layernorm(s, prec, c->dx, L.ln2_w, L.ln2_b, c->dxn, nb, (int)d); }
+            {
+                Prof pr(c, WH_KG_DEC_GEMM);
+                a = SkinnyArgs();
+                a.X = c->dxn; a.ldx = d; a.W = L.cq_w; a.bias = L.cq_b; a.C = c->dq; a.ldc = d;
+                a.M = nb; a.N = (int)d; a.K = (int)d;
+                wh_launch_skinny(s, prec, false, a);
+            }
+            {
+                Prof pr(c, WH_KG_DEC_CROSS_ATTN);
+                wh_launch_dec_cross_attn(s, prec, c->dq, (char*)c->cross_kv + (2 * l) * kv_stride * esz,
+                                         (char*)c->cross_kv + (2 * l + 1) * kv_stride * esz, c->cpart, c->cml, (int)S,
+                                         (int)d, D.n_heads, c->cross_splits, nb);
+            }
+            { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_cross_combine(s, prec, c->cpart, c->cml, c->datt, (int)d, D.n_heads, c->cross_splits, nb); }
+            {
+                Prof pr(c, WH_KG_DEC_GEMM);
+                a = SkinnyArgs();
+                a.X = c->datt; a.ldx = d; a.W = L.co_w; a.bias = L.co_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
+                a.M = nb; a.N = (int)d; a.K = (int)d;
+                wh_launch_skinny(s, prec, true, a);
+            }
+            { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_layernorm(s, prec, c->dx, L.ln3_w, L.ln3_b, c->dxn, nb, (int)d); }
+            {
+                Prof pr(c, WH_KG_DEC_GEMM);
+                a = SkinnyArgs();
+                a.X = c->dxn; a.ldx = d; a.W = L.fc1_w; a.bias = L.fc1_b; a.act = 1; a.C = c->dh; a.ldc = F;
+                a.M = nb; a.N = (int)F; a.K = (int)d;
+                wh_launch_skinny(s, prec, false, a);
+                a = SkinnyArgs();
+                a.X = c->dh; a.ldx = F; a.W = L.fc2_w; a.bias = L.fc2_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
+                a.M = nb; a.N = (int)d; a.K = (int)F;
+                wh_launch_skinny(s, prec, true, a);
+            }
+        }
+        if (step >= P - 1) {  // this position produces a token: final LN, tied LM head, masked argmax
+            { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_layernorm(s, prec, c->dx, m->dec_ln_w, m->dec_ln_b, c->dxn, nb, (int)d); }
+            {
+                Prof pr(c, WH_KG_DEC_GEMM);
+                SkinnyArgs a;
+                a.X = c->dxn; a.ldx = d; a.W = m->tok_emb; a.M = nb; a.N = D.vocab; a.K = (int)d;
+                a.pos_p = c->pos; a.n_prompt = P; a.mask_first = c->mask_first; a.mask_base = c->mask_base;
+                a.logits = d_logits; a.logits_rows = (int)logits_rows; a.part_val = c->part_val; a.part_idx = c->part_idx;
+                wh_launch_lm_head(s, prec, a);
+            }
+            { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_argmax_finish(s, c->part_val, c->part_idx, n_tiles, c->pos, st, nb); }
+        }
+        wh_launch_step_advance(s, c->pos);
+        // EOT early-out (src/main.rs:781-783, 820-822): poll the done flags every 8 generated tokens
+        const int gen = step - (P - 1);
+        if (gen >= 0 && (gen & 7) == 7 && step + 1 < total_pos) {
+            CTX_HIP(c, hipMemcpyAsync(done_h.data(), c->done, nb * 4, hipMemcpyDeviceToHost, s));
+            CTX_HIP(c, hipStreamSynchronize(s));
+            bool all = true;
+            for (int b = 0; b < nb; b++) all = all && done_h[b];
+            if (all) break;
+        }
+    }
+    CTX_HIP(c, hipEventRecord(c->ev[3], s));
+    // results
+    std::vector<int> toks((size_t)nb * ld);
+    const double t0 = now_s();
+    CTX_HIP(c, hipMemcpyAsync(toks.data(), c->out_tokens, toks.size() * 4, hipMemcpyDeviceToHost, s));
+    CTX_HIP(c, hipMemcpyAsync(nout.data(), c->n_out, nb * 4, hipMemcpyDeviceToHost, s));
+    CTX_HIP(c, hipStreamSynchronize(s));
+    CTX_HIP(c, hipGetLastError());
+    for (int b = 0; b < nb; b++) {
+        n_tokens_out[b] = (size_t)nout[b];
+        for (int i = 0; i < nout[b]; i++) tokens_out[(size_t)b * tok_stride + i] = toks[(size_t)b * ld + i];
+    }
+    if (logits_out) {
+        for (int b = 0; b < nb; b++) {
+            const size_t rows = (size_t)nout[b] - P;
+            CTX_HIP(c, hipMemcpy(logits_out + (size_t)b * logits_rows * D.vocab, d_logits + (size_t)b * logits_rows * D.vocab,
+                                 std::min(rows, logits_rows) * D.vocab * 4, hipMemcpyDeviceToHost));
+        }
+    }
+    c->timing.d2h_s = now_s() - t0;
+    return WH_OK;
+}
+
+// mel of nb clips resident in c->pcm (n samples each in c->d_nsamp) → conv1 operand in c->melT
+int run_mel_batch(wh_ctx* c, int nb) {
+    wh_model* m = c->m;
+    hipStream_t s = c->stream;
+    CTX_HIP(c, hipMemsetAsync(c->d_gmax, 0, nb * 4, s));
+    {
+        Prof p(c, WH_KG_MEL);
+        wh_launch_mel_stft(s, c->pcm, WH_CLIP_SAMPLES, c->d_nsamp, nb, WH_N_FRAMES, m->mel_tw, m->mel_win, m->mel_fbT,
+                           m->dims.n_mels, c->raw, (long)m->dims.n_mels * RAW_LD, RAW_LD, c->d_gmax);
+    }
+    {
+        Prof p(c, WH_KG_MEL);
+        if (m->prec == WH_PREC_F32)
+            wh_launch_mel_tokens<float>(s, c->raw, (long)m->dims.n_mels * RAW_LD, RAW_LD, nullptr, nullptr, c->d_nframes,
+                                        c->d_gmax, 0, m->dims.n_mels, nb, (float*)c->melT, (long)TOK_ROWS * m->dims.n_mels);
+        else
+            wh_launch_mel_tokens<bf16>(s, c->raw, (long)m->dims.n_mels * RAW_LD, RAW_LD, nullptr, nullptr, c->d_nframes,
+                                       c->d_gmax, 0, m->dims.n_mels, nb, (bf16*)c->melT, (long)TOK_ROWS * m->dims.n_mels);
+    }
+    return WH_OK;
+}
+
+int finish_timing(wh_ctx* c, double t_start) {
+    float a = 0, b = 0, d = 0;
+    hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
+    hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
+    hipEventElapsedTime(&d, c->ev[2], c->ev[3]);
+    c->timing.preprocess_s = a * 1e-3;
+    c->timing.encode_s = b * 1e-3;
+    c->timing.decode_s = d * 1e-3;
+    c->timing.total_s = now_s() - t_start;
+    prof_collect(c);
+    return WH_OK;
+}
+
+int check_params(wh_ctx* c, const wh_decode_params* p) {
+    if (!p) return fail(c, WH_ERR_ARG, "decode params are NULL");
+    if ((p->n_suppress && !p->suppress) || (p->n_begin_suppress && !p->begin_suppress) || (p->n_forced && !p->forced))
+        return fail(c, WH_ERR_ARG, "decode params: NULL list with non-zero length");
+    return WH_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int wh_abi_version(void) { return WH_ABI_VERSION; }
+
+int wh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int wh_synthetic_weights(const char* preset, uint64_t seed, float* out, size_t cap, size_t* n_out) {
+    wh_dims dims{};
+    if (!preset || !wh_preset_dims(preset, &dims)) { wh_set_error("unknown synthetic preset"); return WH_ERR_ARG; }
+    std::vector<float> w;
+    wh_synth_weights(dims, seed, w);
+    if (n_out) *n_out = w.size();
+    if (out) {
+        if (cap < w.size()) { wh_set_error("buffer too small"); return WH_ERR_ARG; }
+        memcpy(out, w.data(), w.size() * 4);
+    }
+    return WH_OK;
+}
+
+size_t wh_mel_frames(size_t n) {  // src/main.rs:444-452
+    size_t nf = 1 + n / 160;
+    if (nf > 1) nf -= 1;
+    return nf;
+}
+
+int wh_model_load(const char* spec, int device, int precision, wh_model** out) {
+    if (!spec || !out) { wh_set_error("wh_model_load: NULL argument"); return WH_ERR_ARG; }
+    *out = nullptr;
+    std::string s(spec);
+    wh_dims dims{};
+    std::vector<float> master;
+    if (s.rfind("synthetic:", 0) == 0) {
+        size_t c2 = s.find(':', 10);
+        std::string preset = s.substr(10, c2 == std::string::npos ? std::string::npos : c2 - 10);
+        uint64_t seed = c2 == std::string::npos ? 0 : strtoull(s.c_str() + c2 + 1, nullptr, 10);
+        if (!wh_preset_dims(preset, &dims)) { wh_set_error("unknown synthetic preset '%s'", preset.c_str()); return WH_ERR_ARG; }
+        wh_synth_weights(dims, seed, master);
+    } else {
+        int rc = wh_load_model_dir(s, &dims, master);
+        if (rc) return rc;
+    }
+    return wh_model_build(dims, std::move(master), device, precision, out);
+}
+
+int wh_model_create(const wh_dims* dims, const float* weights, size_t n, int device, int precision, wh_model** out) {
+    if (!dims || !weights || !out) { wh_set_error("wh_model_create: NULL argument"); return WH_ERR_ARG; }
+    *out = nullptr;
+    std::vector<float> master(weights, weights + n);
+    return wh_model_build(*dims, std::move(master), device, precision, out);
+}
+
+void wh_model_free(wh_model* m) {
+    if (!m) return;
+    if (m->arena) hipFree(m->arena);
+    delete m;
+}
+
+int wh_model_get_dims(const wh_model* m, wh_dims* out) {
+    if (!m || !out) return WH_ERR_ARG;
+    *out = m->dims;
+    return WH_OK;
+}
+int wh_model_precision(const wh_model* m) { return m ? m->prec : -1; }
+
+int wh_model_export_tensor(const wh_model* m, const char* name, float* out, size_t cap, size_t* n_out) {
+    if (!m || !name) return WH_ERR_ARG;
+    auto it = m->index.find(name);
+    if (it == m->index.end()) { wh_set_error("no tensor named %s", name); return WH_ERR_ARG; }
+    if (n_out) *n_out = it->second.second;
+    if (out) {
+        if (cap < it->second.second) { wh_set_error("export buffer too small"); return WH_ERR_ARG; }
+        memcpy(out, m->master.data() + it->second.first, it->second.second * 4);
+    }
+    return WH_OK;
+}
+
+int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
+    if (!m || !out) { wh_set_error("wh_ctx_create: NULL argument"); return WH_ERR_ARG; }
+    *out = nullptr;
+    if (max_batch < 1 || max_batch > 64) { wh_set_error("max_batch must be 1..64"); return WH_ERR_ARG; }
+    WH_HIP_CHECK(hipSetDevice(m->device));
+    auto* c = new wh_ctx();
+    c->m = m;
+    c->max_batch = max_batch;
+    const wh_dims& D = m->dims;
+    const size_t B = max_batch, d = D.d_model, S = D.n_audio_ctx, F = D.ffn, C = D.n_mels, esz = m->esz;
+    const size_t Ld = D.dec_layers, H = D.n_heads, TC = D.n_text_ctx;
+    c->ldv = (int)align_up(S, 64);
+    c->tok_ld = D.n_text_ctx + 1;
+    // enough workgroups to cover the chip at small batch, no more than 16 key ranges
+    c->cross_splits = (int)std::min<size_t>(16, std::max<size_t>(1, 512 / B));
+    const size_t n_tiles = (D.vocab + 15) / 16;
+    Carver cv;
+    const size_t o_pcm = cv.take(B * WH_CLIP_SAMPLES * 4), o_raw = cv.take(B * C * RAW_LD * 4);
+    const size_t o_melstage = cv.take(C * WH_N_FRAMES * 4);
+    const size_t o_melT = cv.take((B * TOK_ROWS * C + 256) * esz), o_h1 = cv.take((B * H1_ROWS * d + 256) * esz);
+    const size_t o_x = cv.take(B * S * d * 4), o_xn = cv.take(B * S * d * esz), o_qk = cv.take(B * S * 2 * d * esz);
+    const size_t o_vT = cv.take(B * d * c->ldv * esz), o_att = cv.take(B * S * d * esz), o_h = cv.take(B * S * F * esz);
+    const size_t o_enc = cv.take(B * S * d * esz), o_encf = cv.take(B * S * d * 4);
+    const size_t o_ckv = cv.take(Ld * 2 * B * S * d * esz);
+    const size_t o_sk = cv.take(Ld * B * H * TC * WH_HEAD_DIM * esz), o_sv = cv.take(Ld * B * H * TC * WH_HEAD_DIM * esz);
+    const size_t o_dx = cv.take(B * d * 4), o_dxn = cv.take(B * d * esz), o_dqkv = cv.take(B * 3 * d * esz);
+    const size_t o_datt = cv.take(B * d * esz), o_dq = cv.take(B * d * esz), o_dh = cv.take(B * F * esz);
+    const size_t o_cpart = cv.take(B * c->cross_splits * d * 4), o_cml = cv.take(B * c->cross_splits * H * 2 * 4);
+    const size_t o_pv = cv.take(B * n_tiles * 4), o_pi = cv.take(B * n_tiles * 4);
+    const size_t o_feed = cv.take(B * c->tok_ld * 4), o_out = cv.take(B * c->tok_ld * 4);
+    const size_t o_nout = cv.take(B * 4), o_done = cv.take(B * 4), o_forced = cv.take(TC * 4), o_pos = cv.take(4);
+    const size_t o_m1 = cv.take((D.vocab / 32 + 1) * 4), o_m2 = cv.take((D.vocab / 32 + 1) * 4);
+    const size_t o_ns = cv.take(B * 4), o_nf = cv.take(B * 4), o_si = cv.take(B * 4), o_fs = cv.take(B * 4), o_gm = cv.take(B * 4);
+    c->ws_bytes = cv.off;
+    hipError_t he = hipMalloc((void**)&c->ws, c->ws_bytes);
+    if (he != hipSuccess) { delete c; return wh_fail_hip(he, "hipMalloc(workspace)", __FILE__, __LINE__); }
+    he = hipMemset(c->ws, 0, c->ws_bytes);  // conv zero rows, V^T key padding, caches
+    if (he != hipSuccess) { hipFree(c->ws); delete c; return wh_fail_hip(he, "hipMemset(workspace)", __FILE__, __LINE__); }
+    char* w = c->ws;
+    c->pcm = (float*)(w + o_pcm); c->raw = (float*)(w + o_raw); c->mel_stage = (float*)(w + o_melstage);
+    c->melT = w + o_melT; c->h1 = w + o_h1; c->x = (float*)(w + o_x); c->xn = w + o_xn; c->qk = w + o_qk;
+    c->vT = w + o_vT; c->att = w + o_att; c->hbuf = w + o_h; c->enc_out = w + o_enc; c->enc_out_f32 = (float*)(w + o_encf);
+    c->cross_kv = w + o_ckv; c->self_k = w + o_sk; c->self_v = w + o_sv;
+    c->dx = (float*)(w + o_dx); c->dxn = w + o_dxn; c->dqkv = w + o_dqkv; c->datt = w + o_datt; c->dq = w + o_dq; c->dh = w + o_dh;
+    c->cpart = (float*)(w + o_cpart); c->cml = (float*)(w + o_cml); c->part_val = (float*)(w + o_pv); c->part_idx = (int*)(w + o_pi);
+    c->feed = (int*)(w + o_feed); c->out_tokens = (int*)(w + o_out); c->n_out = (int*)(w + o_nout); c->done = (int*)(w + o_done);
+    c->forced = (int*)(w + o_forced); c->pos = (int*)(w + o_pos);
+    c->mask_first = (unsigned*)(w + o_m1); c->mask_base = (unsigned*)(w + o_m2);
+    c->d_nsamp = (int*)(w + o_ns); c->d_nframes = (int*)(w + o_nf); c->d_src_index = (int*)(w + o_si);
+    c->d_frame_start = (int*)(w + o_fs); c->d_gmax = (unsigned*)(w + o_gm);
+    he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (he != hipSuccess) { hipFree(c->ws); delete c; return wh_fail_hip(he, "hipStreamCreate", __FILE__, __LINE__); }
+    for (auto& e : c->ev) hipEventCreate(&e);
+    // the cross-attention kernel may need more than the default dynamic LDS
+    *out = c;
+    return WH_OK;
+}
+
+void wh_ctx_free(wh_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->m->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (int g = 0; g < WH_KG_COUNT; g++)
+        for (auto& e : c->prof_events[g]) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto& e : c->ev)
+        if (e) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->ws) hipFree(c->ws);
+    if (c->pcm_long) hipFree(c->pcm_long);
+    if (c->raw_long) hipFree(c->raw_long);
+    if (c->mel_out_long) hipFree(c->mel_out_long);
+    if (c->logits) hipFree(c->logits);
+    delete c;
+}
+
+const char* wh_last_error(const wh_ctx* c) { return c ? c->err.c_str() : wh_global_error().c_str(); }
+
+int wh_get_timings(const wh_ctx* c, wh_timing* out) {
+    if (!c || !out) return WH_ERR_ARG;
+    *out = c->timing;
+    return WH_OK;
+}
+
+int wh_profile_enable(wh_ctx* c, int enable) {
+    if (!c) return WH_ERR_ARG;
+    c->prof = enable != 0;
+    return WH_OK;
+}
+int wh_profile_get(const wh_ctx* c, double* ms, int64_t* launches) {
+    if (!c || !ms || !launches) return WH_ERR_ARG;
+    for (int g = 0; g < WH_KG_COUNT; g++) { ms[g] = c->prof_ms[g]; launches[g] = c->prof_launches[g]; }
+    return WH_OK;
+}
+
+// grow the whole-file buffers to hold n samples / nf frames
+static int ensure_long(wh_ctx* c, size_t n, size_t nf) {
+    const size_t C = c->m->dims.n_mels;
+    if (n > c->pcm_cap) {
+        if (c->pcm_long) hipFree(c->pcm_long);
+        c->pcm_long = nullptr; c->pcm_cap = 0;
+        CTX_HIP(c, hipMalloc((void**)&c->pcm_long, n * 4));
+        c->pcm_cap = n;
+    }
+    const size_t nfp = align_up(nf, 16);
+    if (nfp > c->raw_long_cap) {
+        if (c->raw_long) hipFree(c->raw_long);
+        if (c->mel_out_long) hipFree(c->mel_out_long);
+        c->raw_long = c->mel_out_long = nullptr; c->raw_long_cap = 0;
+        CTX_HIP(c, hipMalloc((void**)&c->raw_long, C * nfp * 4));
+        CTX_HIP(c, hipMalloc((void**)&c->mel_out_long, C * nfp * 4));
+        c->raw_long_cap = nfp;
+    }
+    return WH_OK;
+}
+
+// whole-file raw log-mel into c->raw_long (row stride = align16(frames)); returns frames
+static int whole_file_mel(wh_ctx* c, const float* pcm, size_t n, size_t* nf_out, size_t* ld_out) {
+    if (n == 0) return fail(c, WH_ERR_EMPTY_AUDIO, "Empty audio");  // src/main.rs:414-416
+    if (!pcm) return fail(c, WH_ERR_ARG, "pcm is NULL");
+    if (n > 0x7fffffffu) return fail(c, WH_ERR_ARG, "audio longer than 2^31 samples");
+    const size_t nf = wh_mel_frames(n), ld = align_up(nf, 16);
+    int rc = ensure_long(c, n, nf);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    const int ni = (int)n, nfi = (int)nf;
+    CTX_HIP(c, hipMemcpyAsync(c->pcm_long, pcm, n * 4, hipMemcpyHostToDevice, s));
+    CTX_HIP(c, hipMemcpyAsync(c->d_nsamp, &ni, 4, hipMemcpyHostToDevice, s));
+    CTX_HIP(c, hipMemcpyAsync(c->d_nframes, &nfi, 4, hipMemcpyHostToDevice, s));
+    CTX_HIP(c, hipMemsetAsync(c->d_gmax, 0, 4, s));
+    CTX_HIP(c, hipStreamSynchronize(s));
+    {
+        Prof p(c, WH_KG_MEL);
+        wh_launch_mel_stft(s, c->pcm_long, 0, c->d_nsamp, 1, (long)nf, c->m->mel_tw, c->m->mel_win, c->m->mel_fbT,
+                           c->m->dims.n_mels, c->raw_long, 0, (long)ld, c->d_gmax);
+    }
+    *nf_out = nf;
+    *ld_out = ld;
+    return WH_OK;
+}
+
+int wh_log_mel(wh_ctx* c, const float* pcm, size_t n, float* mel_out, size_t cap_frames, size_t* n_frames_out) {
+    if (!c) return WH_ERR_ARG;
+    CTX_HIP(c, hipSetDevice(c->m->device));
+    prof_reset(c);
+    const double t0 = now_s();
+    size_t nf = 0, ld = 0;
+    int rc = whole_file_mel(c, pcm, n, &nf, &ld);
+    if (rc) return rc;
+    if (n_frames_out) *n_frames_out = nf;
+    if (!mel_out || cap_frames < nf) return fail(c, WH_ERR_ARG, "mel_out too small: %zu frames needed", nf);
+    wh_launch_mel_norm(c->stream, c->raw_long, (long)ld, c->d_gmax, c->m->dims.n_mels, (long)nf, c->mel_out_long);
+    CTX_HIP(c, hipMemcpyAsync(mel_out, c->mel_out_long, (size_t)c->m->dims.n_mels * nf * 4, hipMemcpyDeviceToHost, c->stream));
+    CTX_HIP(c, hipStreamSynchronize(c->stream));
+    CTX_HIP(c, hipGetLastError());
+    c->timing = wh_timing{};
+    c->timing.preprocess_s = c->timing.total_s = now_s() - t0;
+    prof_collect(c);
+    return WH_OK;
+}
+
+int wh_encode(wh_ctx* c, const float* mel, float* enc_out) {
+    if (!c) return WH_ERR_ARG;
+    if (!mel) return fail(c, WH_ERR_BAD_SHAPE, "wh_encode: mel is NULL (expected [n_mels][3000])");
+    CTX_HIP(c, hipSetDevice(c->m->device));
+    prof_reset(c);
+    const double t0 = now_s();
+    const wh_dims& D = c->m->dims;
+    hipStream_t s = c->stream;
+    const int nf = WH_N_FRAMES;
+    CTX_HIP(c, hipMemcpyAsync(c->mel_stage, mel, (size_t)D.n_mels * WH_N_FRAMES * 4, hipMemcpyHostToDevice, s));
+    CTX_HIP(c, hipMemcpyAsync(c->d_nframes, &nf, 4, hipMemcpyHostToDevice, s));
+    CTX_HIP(c, hipStreamSynchronize(s));
+    CTX_HIP(c, hipEventRecord(c->ev[1], s));
+    if (c->m->prec == WH_PREC_F32)
+        wh_launch_mel_tokens<float>(s, c->mel_stage, 0, WH_N_FRAMES, nullptr, nullptr, c->d_nframes, nullptr, 1, D.n_mels, 1,
+                                    (float*)c->melT, (long)TOK_ROWS * D.n_mels);
+    else
+        wh_launch_mel_tokens<bf16>(s, c->mel_stage, 0, WH_N_FRAMES, nullptr, nullptr, c->d_nframes, nullptr, 1, D.n_mels, 1,
+                                   (bf16*)c->melT, (long)TOK_ROWS * D.n_mels);
+    int rc = run_encoder(c, 1, enc_out != nullptr);
+    if (rc) return rc;
+    CTX_HIP(c, hipEventRecord(c->ev[2], s));
+    if (enc_out)
+        CTX_HIP(c, hipMemcpyAsync(enc_out, c->enc_out_f32, (size_t)D.n_audio_ctx * D.d_model * 4, hipMemcpyDeviceToHost, s));
+    CTX_HIP(c, hipStreamSynchronize(s));
+    CTX_HIP(c, hipGetLastError());
+    float ms = 0;
+    hipEventElapsedTime(&ms, c->ev[1], c->ev[2]);
+    c->timing = wh_timing{};
+    c->timing.encode_s = ms * 1e-3;
+    c->timing.total_s = now_s() - t0;
+    prof_collect(c);
+    return WH_OK;
+}
+
+int wh_decode_greedy(wh_ctx* c, const wh_decode_params* p, int64_t* tokens_out, size_t cap_tokens, size_t* n_tokens_out,
+                     float* logits_out, size_t cap_logits_rows) {
+    if (!c) return WH_ERR_ARG;
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    if (!c->have_enc) return fail(c, WH_ERR_STATE, "Missing cached decoder input: encoder states (call wh_encode first)");
+    if (!tokens_out || !n_tokens_out || cap_tokens < p->n_prompt + p->max_new_tokens)
+        return fail(c, WH_ERR_ARG, "tokens_out needs capacity n_prompt + max_new_tokens");
+    if (logits_out && cap_logits_rows < p->max_new_tokens) return fail(c, WH_ERR_ARG, "logits_out needs max_new_tokens rows");
+    CTX_HIP(c, hipSetDevice(c->m->device));
+    prof_reset(c);
+    const double t0 = now_s();
+    CTX_HIP(c, hipEventRecord(c->ev[2], c->stream));
+    rc = run_decode(c, 1, p, tokens_out, cap_tokens, n_tokens_out, logits_out, p->max_new_tokens);
+    if (rc) return rc;
+    float ms = 0;
+    hipEventElapsedTime(&ms, c->ev[2], c->ev[3]);
+    const double d2h = c->timing.d2h_s;
+    c->timing = wh_timing{};
+    c->timing.decode_s = ms * 1e-3;
+    c->timing.d2h_s = d2h;
+    c->timing.total_s = now_s() - t0;
+    prof_collect(c);
+    return WH_OK;
+}
+
+static int transcribe_resident(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out, size_t* n_tokens_out,
+                               double t_start) {
+    hipStream_t s = c->stream;
+    CTX_HIP(c, hipEventRecord(c->ev[0], s));
+    int rc = run_mel_batch(c, nb);
+    if (rc) return rc;
+    CTX_HIP(c, hipEventRecord(c->ev[1], s));
+    rc = run_encoder(c, nb, false);
+    if (rc) return rc;
+    CTX_HIP(c, hipEventRecord(c->ev[2], s));
+    rc = run_decode(c, nb, p, tokens_out, p->n_prompt + p->max_new_tokens, n_tokens_out, nullptr, 0);
+    if (rc) return rc;
+    return finish_timing(c, t_start);
+}
+
+int wh_transcribe_batch(wh_ctx* c, const wh_clip* clips, size_t n_clips, const wh_decode_params* p, int64_t* tokens_out,
+                        size_t* n_tokens_out) {
+    if (!c) return WH_ERR_ARG;
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    if (!clips || !tokens_out || !n_tokens_out) return fail(c, WH_ERR_ARG, "NULL argument");
+    if (n_clips == 0 || n_clips > (size_t)c->max_batch) return fail(c, WH_ERR_ARG, "n_clips must be 1..max_batch (%d)", c->max_batch);
+    CTX_HIP(c, hipSetDevice(c->m->device));
+    prof_reset(c);
+    const double t0 = now_s();
+    hipStream_t s = c->stream;
+    std::vector<int> ns(n_clips), nf(n_clips);
+    for (size_t i = 0; i < n_clips; i++) {
+        if (clips[i].n_samples == 0) return fail(c, WH_ERR_EMPTY_AUDIO, "Empty audio");
+        if (!clips[i].pcm) return fail(c, WH_ERR_ARG, "clip %zu: pcm is NULL", i);
+        if (clips[i].n_samples > WH_CLIP_SAMPLES) return fail(c, WH_ERR_ARG, "clip %zu longer than one 30 s window; use wh_transcribe_longform", i);
+        ns[i] = (int)clips[i].n_samples;
+        nf[i] = (int)wh_mel_frames(clips[i].n_samples);
+        CTX_HIP(c, hipMemcpyAsync(c->pcm + i * WH_CLIP_SAMPLES, clips[i].pcm, clips[i].n_samples * 4, hipMemcpyHostToDevice, s));
+    }
+    CTX_HIP(c, hipMemcpyAsync(c->d_nsamp, ns.data(), n_clips * 4, hipMemcpyHostToDevice, s));
+    CTX_HIP(c, hipMemcpyAsync(c->d_nframes, nf.data(), n_clips * 4, hipMemcpyHostToDevice, s));
+    CTX_HIP(c, hipStreamSynchronize(s));
+    c->timing = wh_timing{};
+    c->timing.h2d_s = now_s() - t0;
+    return transcribe_resident(c, (int)n_clips, p, tokens_out, n_tokens_out, t0);
+}
+
+int wh_transcribe_batch_device(wh_ctx* c, const float* d_pcm, size_t n_clips, const wh_decode_params* p,
+                               int64_t* tokens_out, size_t* n_tokens_out) {
+    if (!c) return WH_ERR_ARG;
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    if (!d_pcm || !tokens_out || !n_tokens_out) return fail(c, WH_ERR_ARG, "NULL argument");
+    if (n_clips == 0 || n_clips > (size_t)c->max_batch) return fail(c, WH_ERR_ARG, "n_clips must be 1..max_batch (%d)", c->max_batch);
+    CTX_HIP(c, hipSetDevice(c->m->device));
+    prof_reset(c);
+    const double t0 = now_s();
+    hipStream_t s = c->stream;
+    std::vector<int> ns(n_clips, WH_CLIP_SAMPLES), nf(n_clips, WH_N_FRAMES);
+    CTX_HIP(c, hipMemcpyAsync(c->d_nsamp, ns.data(), n_clips * 4, hipMemcpyHostToDevice, s));
+    CTX_HIP(c, hipMemcpyAsync(c->d_nframes, nf.data(), n_clips * 4, hipMemcpyHostToDevice, s));
+    CTX_HIP(c, hipStreamSynchronize(s));
+    float* saved = c->pcm;
+    c->pcm = const_cast<float*>(d_pcm);  // kernels only read it
+    c->timing = wh_timing{};
+    rc = transcribe_resident(c, (int)n_clips, p, tokens_out, n_tokens_out, t0);
+    c->pcm = saved;
+    return rc;
+}
+
+int wh_longform_plan(size_t n_samples, double chunk_length_s, double overlap_s, size_t* offsets, size_t cap,
+                     size_t* n_chunks) {  // src/main.rs:858-861, 875-882
+    if (!n_chunks) return WH_ERR_ARG;
+    const size_t sr = 16000;
+    const size_t chunk_len = (size_t)llround((double)(float)chunk_length_s * (double)sr);
+    const size_t overlap = (size_t)llround((double)(float)overlap_s * (double)sr);
+    size_t step = chunk_len > overlap ? chunk_len - overlap : 0;
+    if (step < 1) step = 1;
+    size_t n = 0, pos = 0;
+    while (pos < n_samples) {
+        size_t end = std::min(pos + chunk_len, n_samples);
+        if (offsets && n < cap) offsets[n] = pos;
+        n++;
+        if (end == n_samples) break;
+        pos += step;
+    }
+    *n_chunks = n;
+    return (offsets && n > cap) ? WH_ERR_ARG : WH_OK;
+}
+
+int wh_transcribe_longform(wh_ctx* c, const float* pcm, size_t n_samples, double chunk_length_s, double overlap_s,
+                           const wh_decode_params* p, int64_t* tokens_out, size_t* n_tokens_out, size_t cap_chunks,
+                           size_t* n_chunks_out) {
+    if (!c) return WH_ERR_ARG;
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    if (!tokens_out || !n_tokens_out || !n_chunks_out) return fail(c, WH_ERR_ARG, "NULL argument");
+    CTX_HIP(c, hipSetDevice(c->m->device));
+    prof_reset(c);
+    const double t0 = now_s();
+    hipStream_t s = c->stream;
+    size_t nch = 0;
+    wh_longform_plan(n_samples, chunk_length_s, overlap_s, nullptr, 0, &nch);
+    *n_chunks_out = nch;
+    if (n_samples == 0) return fail(c, WH_ERR_EMPTY_AUDIO, "Empty audio");
+    if (nch > cap_chunks) return fail(c, WH_ERR_ARG, "need room for %zu chunks", nch);
+    std::vector<size_t> offs(nch);
+    wh_longform_plan(n_samples, chunk_length_s, overlap_s, offs.data(), nch, &nch);
+    // whole-file mel once: the normalisation max is global over the FILE (src/main.rs:870-872)
+    CTX_HIP(c, hipEventRecord(c->ev[0], s));
+    size_t nf = 0, ld = 0;
+    rc = whole_file_mel(c, pcm, n_samples, &nf, &ld);
+    if (rc) return rc;
+    CTX_HIP(c, hipEventRecord(c->ev[1], s));
+    const size_t stride = p->n_prompt + p->max_new_tokens;
+    const wh_dims& D = c->m->dims;
+    double enc_s = 0, dec_s = 0;
+    for (size_t base = 0; base < nch; base += c->max_batch) {
+        const int nb = (int)std::min<size_t>(c->max_batch, nch - base);
+        std::vector<int> src(nb, 0), fs(nb), nfs(1, (int)nf);
+        for (int i = 0; i < nb; i++) fs[i] = (int)(offs[base + i] / 160);  // frame_start = pos / hop (:895, 950)
+        CTX_HIP(c, hipMemcpyAsync(c->d_src_index, src.data(), nb * 4, hipMemcpyHostToDevice, s));
+        CTX_HIP(c, hipMemcpyAsync(c->d_frame_start, fs.data(), nb * 4, hipMemcpyHostToDevice, s));
+        CTX_HIP(c, hipMemcpyAsync(c->d_nframes, nfs.data(), 4, hipMemcpyHostToDevice, s));
+        CTX_HIP(c, hipStreamSynchronize(s));
+        CTX_HIP(c, hipEventRecord(c->ev[4], s));
+        if (c->m->prec == WH_PREC_F32)
+            wh_launch_mel_tokens<float>(s, c->raw_long, 0, (long)ld, c->d_src_index, c->d_frame_start, c->d_nframes, c->d_gmax, 0,
+                                        D.n_mels, nb, (float*)c->melT, (long)TOK_ROWS * D.n_mels);
+        else
+            wh_launch_mel_tokens<bf16>(s, c->raw_long, 0, (long)ld, c->d_src_index, c->d_frame_start, c->d_nframes, c->d_gmax, 0,
+                                       D.n_mels, nb, (bf16*)c->melT, (long)TOK_ROWS * D.n_mels);
+        rc = run_encoder(c, nb, false);
+        if (rc) return rc;
+        CTX_HIP(c, hipEventRecord(c->ev[2], s));
+        rc = run_decode(c, nb, p, tokens_out + base * stride, stride, n_tokens_out + base, nullptr, 0);
+        if (rc) return rc;
+        float a = 0, b = 0;
+        hipEventElapsedTime(&a, c->ev[4], c->ev[2]);
+        hipEventElapsedTime(&b, c->ev[2], c->ev[3]);
+        enc_s += a * 1e-3;
+        dec_s += b * 1e-3;
+    }
+    float a = 0;
+    hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
+    c->timing = wh_timing{};
+    c->timing.preprocess_s = a * 1e-3;
+    c->timing.encode_s = enc_s;
+    c->timing.decode_s = dec_s;
+    c->timing.total_s = now_s() - t0;
+    prof_collect(c);
+    return WH_OK;
+}
+
+}  // extern "C"

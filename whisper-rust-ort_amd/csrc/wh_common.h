@@ -1,0 +1,97 @@
+// wh_common.h — shared device helpers for the gfx950 kernels (wave64, MFMA 16x16 tiles).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/whisper_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(4))) double f64x4;
+
+#define WH_WAVE 64
+#define WH_HEAD_DIM 64
+
+// ---------------------------------------------------------------------------------------------
+// One "fragment" = 8 consecutive k-elements per lane.  Lane l of a wave holds, for the row/column
+// index (l & 15), the k-range 8*(l>>4) .. 8*(l>>4)+7 of a 32-deep k-slab.
+//   mma16(acc, a, b):  D[i][j] += sum_k A[i][k] * B[k][j]
+//     a = A[i = l&15][k-range],  b = B[k-range][j = l&15]
+//     D layout (all dtypes): column j = l & 15, rows i = 4*(l>>4) + r for r = 0..3 (acc[r]).
+// bf16: one v_mfma_f32_16x16x32_bf16.  f32: eight v_mfma_f32_16x16x4_f32 (exact f32 fma chain);
+// the per-instruction k assignment {8g+e : g=0..3} is a permutation of the slab, identical for
+// both operands, so the contraction is the same sum.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct FragT;
+template <> struct FragT<bf16> { typedef bf16x8 type; };
+template <> struct FragT<float> { typedef f32x8 type; };
+
+template <typename T>
+__device__ __forceinline__ typename FragT<T>::type load_frag(const T* p) {
+    return *reinterpret_cast<const typename FragT<T>::type*>(p);
+}
+
+__device__ __forceinline__ void mma16(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f32x4& acc, const f32x8& a, const f32x8& b) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+}
+
+template <typename T> __device__ __forceinline__ T cvt_out(float v);
+template <> __device__ __forceinline__ float cvt_out<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 cvt_out<bf16>(float v) { return (bf16)v; }  // v_cvt_pk_bf16_f32: RNE, NaN-safe
+
+template <typename T> __device__ __forceinline__ float cvt_in(T v) { return (float)v; }
+
+// store 4 consecutive outputs
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
+}
+__device__ __forceinline__ void store4(bf16* p, float a, float b, float c, float d) {
+    *reinterpret_cast<bf16x4*>(p) = bf16x4{(bf16)a, (bf16)b, (bf16)c, (bf16)d};
+}
+
+// exact (erf) GELU — activation_function "gelu" ([3P] configuration_whisper.py:140)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// order-preserving float <-> uint map for atomicMax on floats of either sign
+__device__ __forceinline__ unsigned f2ord(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __host__ __forceinline__ float ord2f(unsigned u) {
+    unsigned v = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+#ifdef __HIP_DEVICE_COMPILE__
+    return __uint_as_float(v);
+#else
+    float f;
+    __builtin_memcpy(&f, &v, 4);
+    return f;
+#endif
+}
+
+#define WH_HIP_CHECK(expr)                                                                      \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) return wh_fail_hip(_e, #expr, __FILE__, __LINE__);                \
+    } while (0)
+
+int wh_fail_hip(hipError_t e, const char* what, const char* file, int line);
+void wh_set_error(const char* fmt, ...);

@@ -1,0 +1,230 @@
+// wh_gemm.hip — LDS-tiled MFMA GEMM with fused epilogues, and row LayerNorm, for gfx950.
+//
+//   C[m][n] = act( sum_k A[m][k] * W[n][k] + bias ) + R[m][n]
+//
+// Both operands are k-contiguous (activations row-major, weights in torch Linear [out][in]
+// layout), which is exactly the 8-consecutive-k-per-lane MFMA fragment, so tiles go global → LDS →
+// registers with 16-byte accesses and no transposes.  The MFMA is issued with the WEIGHT tile as
+// the row operand, so every lane ends up with 4 consecutive n of one output row: bias/residual
+// loads and the output store are 8/16-byte vector accesses.
+//
+// Row m of A lives at A + (m / m_per) * a_bs + (m % m_per) * lda — this lets the same kernel run
+//   - plain Linear layers over all clips of a batch (m_per = rows per clip),
+//   - Conv1d(k3,p1) and Conv1d(k3,s2,p1) as GEMMs over OVERLAPPING rows of a zero-padded
+//     token-major activation buffer (lda = C_in resp. 2*C_in, K = 3*C_in): no im2col buffer
+//     (encoder ops K2/K3 of SURVEY §2d; [3P] modeling_whisper.py:566-567,618-624),
+//   - per-clip batched products via blockIdx.z strides (V^T projection).
+// It stands in for ONNX Runtime's MLAS GEMM/Conv nodes behind run_encoder
+// (reference src/main.rs:698-707) and the step-0 cross-attention K/V projection (:771-787).
+#include "wh_common.h"
+#include "wh_kernels.h"
+
+namespace {
+
+template <typename T> struct Ldk;               // LDS row stride (elements) for a 32-deep k-slab
+template <> struct Ldk<bf16> { static constexpr int v = 40; };   // 80 B rows
+template <> struct Ldk<float> { static constexpr int v = 36; };  // 144 B rows
+
+template <typename T, typename TO, int BM, int BN>
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
+    constexpr int BK = 32;
+    constexpr int LDK = Ldk<T>::v;
+    constexpr int CPR = BK * (int)sizeof(T) / 16;        // 16-B chunks per tile row: 4 (bf16) / 8 (f32)
+    constexpr int EPC = 16 / (int)sizeof(T);             // elements per chunk
+    constexpr int A_CH = BM * CPR / 256, W_CH = BN * CPR / 256;
+    constexpr int TM = BM / 32, TN = BN / 32;            // 16x16 tiles per wave (2x2 waves)
+    __shared__ __attribute__((aligned(16))) T As[BM * LDK];
+    __shared__ __attribute__((aligned(16))) T Ws[BN * LDK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fl = lane & 15, fg = lane >> 4;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const long z = blockIdx.z;
+    const T* A = (const T*)g.A + z * g.a_zs;
+    const T* W = (const T*)g.W + z * g.w_zs;
+
+    // per-thread source pointers for the staging chunks
+    const T* a_src[A_CH];
+    const T* w_src[W_CH];
+    int a_dst[A_CH], w_dst[W_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; i++) {
+        int c = tid + i * 256, row = c / CPR, col = (c % CPR) * EPC;
+        int m = m0 + row;
+        if (m > g.M - 1) m = g.M - 1;
+        a_src[i] = A + (long)(m / g.m_per) * g.a_bs + (long)(m % g.m_per) * g.lda + col;
+        a_dst[i] = row * LDK + col;
+    }
+#pragma unroll
+    for (int i = 0; i < W_CH; i++) {
+        int c = tid + i * 256, row = c / CPR, col = (c % CPR) * EPC;
+        int n = n0 + row;
+        if (n > g.N - 1) n = g.N - 1;
+        w_src[i] = W + (long)n * g.ldw + col;
+        w_dst[i] = row * LDK + col;
+    }
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    u32x4 a_reg[A_CH], w_reg[W_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; i++) a_reg[i] = *reinterpret_cast<const u32x4*>(a_src[i]);
+#pragma unroll
+    for (int i = 0; i < W_CH; i++) w_reg[i] = *reinterpret_cast<const u32x4*>(w_src[i]);
+
+    const int nk = g.K / BK;
+    for (int kt = 0; kt < nk; kt++) {
+#pragma unroll
+        for (int i = 0; i < A_CH; i++) *reinterpret_cast<u32x4*>(&As[a_dst[i]]) = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < W_CH; i++) *reinterpret_cast<u32x4*>(&Ws[w_dst[i]]) = w_reg[i];
+        __syncthreads();
+        if (kt + 1 < nk) {  // next slab's global loads fly under this slab's MFMAs
+#pragma unroll
+            for (int i = 0; i < A_CH; i++) a_reg[i] = *reinterpret_cast<const u32x4*>(a_src[i] + (long)(kt + 1) * BK);
+#pragma unroll
+            for (int i = 0; i < W_CH; i++) w_reg[i] = *reinterpret_cast<const u32x4*>(w_src[i] + (long)(kt + 1) * BK);
+        }
+        typename FragT<T>::type af[TM], wf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) af[i] = load_frag<T>(&As[(wr * (BM / 2) + i * 16 + fl) * LDK + fg * 8]);
+#pragma unroll
+        for (int j = 0; j < TN; j++) wf[j] = load_frag<T>(&Ws[(wc * (BN / 2) + j * 16 + fl) * LDK + fg * 8]);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) mma16(acc[i][j], wf[j], af[i]);  // D rows = n, cols = m
+        __syncthreads();
+    }
+
+    // epilogue: lane holds n = nb + 4*fg + 0..3 for row m = mb + fl
+    TO* C = (TO*)g.C + z * g.c_zs;
+    const float* R = g.R ? g.R + z * g.r_zs : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int m = m0 + wr * (BM / 2) + i * 16 + fl;
+        if (m >= g.M) continue;
+        const long mb = m / g.m_per, mi = m % g.m_per;
+        TO* crow = C + mb * g.c_bs + mi * g.ldc;
+        const float* rrow = R ? R + mb * g.r_bs + mi * g.ldr : nullptr;
+        const float bm = (g.bias && g.bias_mode == 2) ? g.bias[m] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = n0 + wc * (BN / 2) + j * 16 + fg * 4;
+            if (n >= g.N) continue;
+            const long nc = (long)(n / g.n_per) * g.c_ns + (n % g.n_per);
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (g.bias && g.bias_mode == 1) {
+                f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
+                v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
+            } else {
+                v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm;
+            }
+            if (g.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
+            }
+            if (rrow) {
+                f32x4 r = *reinterpret_cast<const f32x4*>(rrow + n);
+                v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+            }
+            store4(crow + nc, v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// ---- LayerNorm over rows of length d (f32 in, T out); one wave per row -------------------------
+// [3P] torch LayerNorm eps 1e-5, biased variance (modeling_whisper.py:371,377,642,790).
+template <typename TO>
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ b, TO* __restrict__ y, long rows, int d) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + row * d;
+    constexpr int MAXV = 5;  // d <= 1280: 64 lanes * 4 floats * 5
+    f32x4 v[MAXV];
+    float s = 0.0f;
+    const int nv = d >> 8;  // d / 256 full sweeps
+#pragma unroll
+    for (int i = 0; i < MAXV; i++) {
+        if (i < nv) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + (i * 64 + lane) * 4);
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    // tail (d % 256, multiple of 4): used by d = 128 (nano) and 1280 = 5*256 has none
+    const int rem = d & 255;
+    f32x4 tv = {0, 0, 0, 0};
+    const bool has_tail = lane * 4 < rem;
+    if (has_tail) {
+        tv = *reinterpret_cast<const f32x4*>(xr + nv * 256 + lane * 4);
+        s += tv[0] + tv[1] + tv[2] + tv[3];
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; i++) {
+        if (i < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) { float t = v[i][e] - mean; q += t * t; }
+        }
+    }
+    if (has_tail) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) { float t = tv[e] - mean; q += t * t; }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+    TO* yr = y + row * d;
+#pragma unroll
+    for (int i = 0; i < MAXV; i++) {
+        if (i < nv) {
+            const int c = (i * 64 + lane) * 4;
+            f32x4 ww = *reinterpret_cast<const f32x4*>(w + c), bb = *reinterpret_cast<const f32x4*>(b + c);
+            store4(yr + c, (v[i][0] - mean) * rstd * ww[0] + bb[0], (v[i][1] - mean) * rstd * ww[1] + bb[1],
+                   (v[i][2] - mean) * rstd * ww[2] + bb[2], (v[i][3] - mean) * rstd * ww[3] + bb[3]);
+        }
+    }
+    if (has_tail) {
+        const int c = nv * 256 + lane * 4;
+        f32x4 ww = *reinterpret_cast<const f32x4*>(w + c), bb = *reinterpret_cast<const f32x4*>(b + c);
+        store4(yr + c, (tv[0] - mean) * rstd * ww[0] + bb[0], (tv[1] - mean) * rstd * ww[1] + bb[1],
+               (tv[2] - mean) * rstd * ww[2] + bb[2], (tv[3] - mean) * rstd * ww[3] + bb[3]);
+    }
+}
+
+template <typename T, typename TO>
+void launch_gemm_t(hipStream_t s, const GemmArgs& g) {
+    const long blocks128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;
+    if (blocks128 >= 192) {
+        dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, g.batch);
+        hipLaunchKernelGGL((k_gemm<T, TO, 128, 128>), grid, dim3(256), 0, s, g);
+    } else {
+        dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, g.batch);
+        hipLaunchKernelGGL((k_gemm<T, TO, 64, 64>), grid, dim3(256), 0, s, g);
+    }
+}
+
+}  // namespace
+
+void wh_launch_gemm(hipStream_t s, int prec, bool out_f32, const GemmArgs& g) {
+    if (prec == WH_PREC_F32) {
+        launch_gemm_t<float, float>(s, g);
+    } else {
+        if (out_f32) launch_gemm_t<bf16, float>(s, g);
+        else launch_gemm_t<bf16, bf16>(s, g);
+    }
+}
+
+void wh_launch_layernorm(hipStream_t s, int prec, const float* x, const float* w, const float* b, void* y, long rows,
+                         int d) {
+    dim3 grid((unsigned)((rows + 3) / 4));
+    if (prec == WH_PREC_F32) hipLaunchKernelGGL(k_layernorm<float>, grid, dim3(256), 0, s, x, w, b, (float*)y, rows, d);
+    else hipLaunchKernelGGL(k_layernorm<bf16>, grid, dim3(256), 0, s, x, w, b, (bf16*)y, rows, d);
+}

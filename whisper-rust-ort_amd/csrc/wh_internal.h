@@ -1,0 +1,115 @@
+// wh_internal.h — wh_model / wh_ctx definitions (internal to libwhisper_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/whisper_hip.h"
+#include "wh_kernels.h"
+
+struct EncLayerDev {
+    void *qk_w, *v_w, *o_w, *fc1_w, *fc2_w;
+    float *qk_b, *v_b, *o_b, *fc1_b, *fc2_b;
+    float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+};
+struct DecLayerDev {
+    void *qkv_w, *o_w, *cq_w, *co_w, *fc1_w, *fc2_w;
+    float *qkv_b, *o_b, *cq_b, *co_b, *fc1_b, *fc2_b;
+    float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *ln3_w, *ln3_b;
+};
+
+struct wh_model {
+    wh_dims dims{};
+    int prec = WH_PREC_BF16;
+    int device = 0;
+    size_t esz = 2;  // bytes per element of the compute dtype
+    // f32 master copy in canonical order (modelspec.tensor_table) + name → (offset, count)
+    std::vector<float> master;
+    std::map<std::string, std::pair<size_t, size_t>> index;
+    // device arena
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    int conv1_k = 0;  // 3*n_mels rounded up to 32
+    void *conv1_w = nullptr, *conv2_w = nullptr, *tok_emb = nullptr, *cross_kv_w = nullptr;
+    float *conv1_b = nullptr, *conv2_b = nullptr, *enc_pos = nullptr, *dec_pos = nullptr, *cross_kv_b = nullptr;
+    float *enc_ln_w = nullptr, *enc_ln_b = nullptr, *dec_ln_w = nullptr, *dec_ln_b = nullptr;
+    std::vector<EncLayerDev> enc;
+    std::vector<DecLayerDev> dec;
+    // log-mel tables
+    double* mel_tw = nullptr;
+    float *mel_win = nullptr, *mel_fbT = nullptr;
+};
+
+struct wh_ctx {
+    wh_model* m = nullptr;
+    int max_batch = 1;
+    hipStream_t stream = nullptr;
+    std::string err;
+    wh_timing timing{};
+    bool have_enc = false;  // encoder states of `enc_batch` clips are resident
+    int enc_batch = 0;
+    // profiling hooks
+    bool prof = false;
+    int prof_group = -1;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[WH_KG_COUNT];
+    size_t prof_used[WH_KG_COUNT] = {0};
+    double prof_ms[WH_KG_COUNT] = {0};
+    int64_t prof_launches[WH_KG_COUNT] = {0};
+    hipEvent_t ev[8] = {nullptr};
+
+    // ---- device workspace (sized for max_batch clips) ----
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    float* pcm = nullptr;       // [B][480000]
+    size_t pcm_cap = 0;         // samples allocated behind `pcm_long` for whole-file mel
+    float* pcm_long = nullptr;  // staged-API / long-form whole file (grown on demand)
+    float* raw_long = nullptr;  // [n_mels][frames] raw log-mel of a whole file (grown on demand)
+    size_t raw_long_cap = 0;    // frames
+    float* mel_out_long = nullptr;
+    int* d_nsamp = nullptr;     // [B]
+    int* d_nframes = nullptr;   // [B]
+    int* d_src_index = nullptr; // [B]
+    int* d_frame_start = nullptr;
+    unsigned* d_gmax = nullptr; // [B]
+    float* raw = nullptr;       // [B][n_mels][3008]
+    float* mel_stage = nullptr; // [n_mels][3000] staged-API mel upload
+    void* melT = nullptr;       // [B][3002][n_mels] (+slack)
+    void* h1 = nullptr;         // [B][3001][d]
+    float* x = nullptr;         // [B][S][d] f32 residual stream
+    void* xn = nullptr;         // [B][S][d]
+    void* qk = nullptr;         // [B][S][2d]
+    void* vT = nullptr;         // [B][d][ldv]
+    void* att = nullptr;        // [B][S][d]
+    void* hbuf = nullptr;       // [B][S][ffn]
+    void* enc_out = nullptr;    // [B][S][d] compute dtype (cross-KV GEMM operand)
+    float* enc_out_f32 = nullptr;  // [B][S][d] f32 (API output)
+    int ldv = 0;
+    void* cross_kv = nullptr;   // [Ld][2][B][S][d]
+    void *self_k = nullptr, *self_v = nullptr;  // [Ld][B][H][TC][64]
+    // decode step buffers
+    float* dx = nullptr;        // [B][d]
+    void* dxn = nullptr;        // [B][d]
+    void* dqkv = nullptr;       // [B][3d]
+    void* datt = nullptr;       // [B][d]
+    void* dq = nullptr;         // [B][d]
+    void* dh = nullptr;         // [B][ffn]
+    float* cpart = nullptr;     // [B][splits][d]
+    float* cml = nullptr;       // [B][splits][H][2]
+    float* part_val = nullptr;  // [B][n_tiles]
+    int* part_idx = nullptr;
+    int *feed = nullptr, *out_tokens = nullptr, *n_out = nullptr, *done = nullptr, *forced = nullptr, *pos = nullptr;
+    unsigned *mask_first = nullptr, *mask_base = nullptr;
+    float* logits = nullptr;    // optional parity buffer (grown on demand)
+    size_t logits_cap = 0;
+    int tok_ld = 0;
+    int cross_splits = 1;
+};
+
+// wh_model.cpp
+int wh_model_build(const wh_dims& dims, std::vector<float>&& master, int device, int precision, wh_model** out);
+void wh_synth_weights(const wh_dims& dims, uint64_t seed, std::vector<float>& out);
+void wh_tensor_table(const wh_dims& dims, std::vector<std::pair<std::string, std::vector<int64_t>>>& out);
+bool wh_preset_dims(const std::string& name, wh_dims* out);
+int wh_load_model_dir(const std::string& dir, wh_dims* dims, std::vector<float>& master);

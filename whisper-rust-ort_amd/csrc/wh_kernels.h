@@ -1,0 +1,89 @@
+// wh_kernels.h — host-side launchers of the gfx950 kernels (internal to libwhisper_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <vector>
+
+struct GemmArgs {
+    const void* A = nullptr;   // [M rows][K], row m at (m / m_per) * a_bs + (m % m_per) * lda
+    long lda = 0, a_bs = 0, a_zs = 0;
+    const void* W = nullptr;   // [N][K] k-contiguous
+    long ldw = 0, w_zs = 0;
+    void* C = nullptr;         // row m at (m / m_per) * c_bs + (m % m_per) * ldc
+    long ldc = 0, c_bs = 0, c_zs = 0;
+    const float* bias = nullptr;
+    int bias_mode = 0;         // 0 none, 1 per column n, 2 per row m
+    const float* R = nullptr;  // f32 residual / positional table, same row addressing with ldr, r_bs
+    long ldr = 0, r_bs = 0, r_zs = 0;
+    int act = 0;               // 1 = erf GELU (applied before the residual add)
+    int M = 0, N = 0, K = 0;
+    int m_per = 1 << 30;
+    int n_per = 1 << 30;       // column n stored at (n / n_per) * c_ns + (n % n_per)
+    long c_ns = 0;
+    int batch = 1;             // gridDim.z, pointer strides *_zs
+};
+
+struct SkinnyArgs {
+    const void* X = nullptr;   // [M][ldx]
+    long ldx = 0;
+    const void* W = nullptr;   // [N][K]
+    const float* bias = nullptr;
+    const float* R = nullptr;  // residual f32 [M][ldr]
+    long ldr = 0;
+    void* C = nullptr;
+    long ldc = 0;
+    int M = 0, N = 0, K = 0, act = 0;
+    // LM-head mode
+    const int* pos_p = nullptr;
+    int n_prompt = 0;
+    const unsigned* mask_first = nullptr;
+    const unsigned* mask_base = nullptr;
+    float* logits = nullptr;   // optional [M][logits_rows][N]
+    int logits_rows = 0;
+    float* part_val = nullptr;
+    int* part_idx = nullptr;
+};
+
+struct DecodeState {
+    int* feed = nullptr;        // [B][tok_ld] input token per position
+    int* out_tokens = nullptr;  // [B][tok_ld] prompt ++ generated
+    int* n_out = nullptr;       // [B]
+    int* done = nullptr;        // [B]
+    const int* forced = nullptr;
+    int n_forced = 0;
+    int n_prompt = 0;
+    int eot = 0;
+    int tok_ld = 0;
+};
+
+void wh_build_mel_tables(int n_mels, std::vector<double>& tw, std::vector<float>& win, std::vector<float>& fbT);
+void wh_launch_mel_stft(hipStream_t s, const float* pcm, long pcm_stride, const int* n_samples, int n_clips,
+                        long max_frames, const double* tw, const float* win, const float* fbT, int n_mels, float* raw,
+                        long raw_clip_stride, long raw_row_stride, unsigned* gmax);
+void wh_launch_mel_norm(hipStream_t s, const float* raw, long raw_row_stride, const unsigned* gmax, int n_mels,
+                        long n_frames, float* out);
+template <typename T>
+void wh_launch_mel_tokens(hipStream_t s, const float* src, long src_clip_stride, long src_row_stride,
+                          const int* src_index, const int* frame_start, const int* n_frames_src, const unsigned* gmax,
+                          int mode, int n_mels, int n_out, T* tok, long tok_clip_stride);
+
+void wh_launch_gemm(hipStream_t s, int prec, bool out_f32, const GemmArgs& g);
+void wh_launch_layernorm(hipStream_t s, int prec, const float* x, const float* w, const float* b, void* y, long rows,
+                         int d);
+void wh_launch_enc_attn(hipStream_t s, int prec, const void* qk, const void* vT, void* out, int n_clips, int S, int d,
+                        int n_heads, int ldv);
+
+void wh_launch_dec_embed(hipStream_t s, int prec, const void* tok_emb, const float* pos_emb, const int* feed,
+                         int feed_ld, const int* pos_p, float* x, int d, int B);
+void wh_launch_skinny(hipStream_t s, int prec, bool out_f32, const SkinnyArgs& a);
+void wh_launch_lm_head(hipStream_t s, int prec, const SkinnyArgs& a);
+void wh_launch_argmax_finish(hipStream_t s, const float* part_val, const int* part_idx, int n_tiles, const int* pos_p,
+                             const DecodeState& st, int B);
+void wh_launch_step_advance(hipStream_t s, int* pos_p);
+void wh_launch_dec_self_attn(hipStream_t s, int prec, const void* qkv, void* kc, void* vc, void* out, const int* pos_p,
+                             int d, int n_heads, int tc, int B);
+size_t wh_cross_attn_smem(int S, int d, int n_heads, int splits);
+void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void* ck, const void* cv, float* part,
+                              float* ml, int S, int d, int n_heads, int splits, int B);
+void wh_launch_cross_combine(hipStream_t s, int prec, const float* part, const float* ml, void* out, int d, int n_heads,
+                             int splits, int B);

@@ -1,0 +1,526 @@
+// wh_model.cpp — model lifecycle: replaces build_session x3 (reference src/main.rs:169-202,
+// 1099-1108).  Sources of weights:
+//   * "synthetic:<preset>:<seed>" — hash-seeded values, bit-identical to
+//     whisper-rust-ort_amd/modelspec.py (no checkpoint exists in this pipeline);
+//   * a directory with config.json + model.safetensors in the HF Whisper layout (what
+//     --onnx-dir would point at once real weights are supplied).
+// The f32 master copy is re-laid-out for the gfx950 kernels: q-scale folded into W_q/b_q, Q|K and
+// Q|K|V fused, conv weights re-ordered tap-major so Conv1d is a GEMM over overlapping rows, all
+// decoder cross-attention K/V projections stacked into one [Ld*2*d][d] matrix, and everything that
+// feeds an MFMA converted to the compute dtype.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/stat.h>
+
+#include <fstream>
+#include <sstream>
+
+#include "wh_common.h"
+#include "wh_internal.h"
+#include "wh_json.h"
+
+// ---- error plumbing -------------------------------------------------------------------------
+static thread_local std::string g_err;
+void wh_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+const std::string& wh_global_error() { return g_err; }
+int wh_fail_hip(hipError_t e, const char* what, const char* file, int line) {
+    wh_set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    return WH_ERR_HIP;
+}
+
+// ---- presets & canonical tensor table (mirror of modelspec.py) -----------------------------
+bool wh_preset_dims(const std::string& name, wh_dims* o) {
+    if (name == "nano") *o = wh_dims{80, 128, 2, 2, 2, 256, 1024, 1500, 448};
+    else if (name == "micro") *o = wh_dims{80, 256, 4, 2, 3, 1024, 4099, 1500, 448};
+    else if (name == "base") *o = wh_dims{80, 512, 8, 6, 6, 2048, 51865, 1500, 448};
+    else if (name == "large-v3") *o = wh_dims{128, 1280, 20, 32, 32, 5120, 51866, 1500, 448};
+    else return false;
+    return true;
+}
+
+typedef std::vector<std::pair<std::string, std::vector<int64_t>>> TensorTable;
+
+void wh_tensor_table(const wh_dims& c, TensorTable& t) {
+    const int64_t d = c.d_model, F = c.ffn;
+    auto attn = [&](const std::string& p) {
+        t.push_back({p + ".q_proj.weight", {d, d}});
+        t.push_back({p + ".q_proj.bias", {d}});
+        t.push_back({p + ".k_proj.weight", {d, d}});
+        t.push_back({p + ".v_proj.weight", {d, d}});
+        t.push_back({p + ".v_proj.bias", {d}});
+        t.push_back({p + ".out_proj.weight", {d, d}});
+        t.push_back({p + ".out_proj.bias", {d}});
+    };
+    auto ln = [&](const std::string& p) {
+        t.push_back({p + ".weight", {d}});
+        t.push_back({p + ".bias", {d}});
+    };
+    auto mlp = [&](const std::string& p) {
+        t.push_back({p + ".fc1.weight", {F, d}});
+        t.push_back({p + ".fc1.bias", {F}});
+        t.push_back({p + ".fc2.weight", {d, F}});
+        t.push_back({p + ".fc2.bias", {d}});
+    };
+    const std::string e = "model.encoder", dd = "model.decoder";
+    t.push_back({e + ".conv1.weight", {d, c.n_mels, 3}});
+    t.push_back({e + ".conv1.bias", {d}});
+    t.push_back({e + ".conv2.weight", {d, d, 3}});
+    t.push_back({e + ".conv2.bias", {d}});
+    t.push_back({e + ".embed_positions.weight", {c.n_audio_ctx, d}});
+    for (int i = 0; i < c.enc_layers; i++) {
+        std::string p = e + ".layers." + std::to_string(i);
+        attn(p + ".self_attn");
+        ln(p + ".self_attn_layer_norm");
+        mlp(p);
+        ln(p + ".final_layer_norm");
+    }
+    ln(e + ".layer_norm");
+    t.push_back({dd + ".embed_tokens.weight", {c.vocab, d}});
+    t.push_back({dd + ".embed_positions.weight", {c.n_text_ctx, d}});
+    for (int i = 0; i < c.dec_layers; i++) {
+        std::string p = dd + ".layers." + std::to_string(i);
+        attn(p + ".self_attn");
+        ln(p + ".self_attn_layer_norm");
+        attn(p + ".encoder_attn");
+        ln(p + ".encoder_attn_layer_norm");
+        mlp(p);
+        ln(p + ".final_layer_norm");
+    }
+    ln(dd + ".layer_norm");
+}
+
+static size_t numel(const std::vector<int64_t>& s) {
+    size_t n = 1;
+    for (auto v : s) n *= (size_t)v;
+    return n;
+}
+static bool ends_with(const std::string& s, const char* suf) {
+    size_t n = strlen(suf);
+    return s.size() >= n && !s.compare(s.size() - n, n, suf);
+}
+
+// ---- hash-seeded values (modelspec.synth_tensor) --------------------------------------------
+static uint64_t fnv1a64(const std::string& s) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (unsigned char c : s) { h ^= c; h *= 0x100000001B3ull; }
+    return h;
+}
+void wh_synth_weights(const wh_dims& c, uint64_t seed, std::vector<float>& out) {
+    TensorTable tt;
+    wh_tensor_table(c, tt);
+    size_t total = 0;
+    for (auto& e : tt) total += numel(e.second);
+    out.resize(total);
+    const uint64_t GOLD = 0x9E3779B97F4A7C15ull;
+    size_t off = 0;
+    for (auto& e : tt) {
+        const std::string& name = e.first;
+        const size_t n = numel(e.second);
+        float* dst = out.data() + off;
+        off += n;
+        if (ends_with(name, "encoder.embed_positions.weight")) {
+            // [3P] modeling_whisper.py sinusoids (:55-64): [sin | cos], float64 evaluation
+            const int64_t len = e.second[0], ch = e.second[1], half = ch / 2;
+            const double inc = log(10000.0) / (double)(half - 1);
+            for (int64_t p = 0; p < len; p++)
+                for (int64_t i = 0; i < half; i++) {
+                    double st = (double)p * exp(-inc * (double)i);
+                    dst[p * ch + i] = (float)sin(st);
+                    dst[p * ch + half + i] = (float)cos(st);
+                }
+            continue;
+        }
+        float offv = 0.0f, amp;
+        if (ends_with(name, "layer_norm.weight")) { offv = 1.0f; amp = 0.1f; }
+        else if (ends_with(name, ".bias")) amp = 0.1f;
+        else if (ends_with(name, "embed_tokens.weight")) amp = 0.2f;
+        else if (ends_with(name, "decoder.embed_positions.weight")) amp = 0.05f;
+        else {
+            size_t fan_in = n / (size_t)e.second[0];
+            amp = (float)sqrt(3.0 / (double)fan_in);
+        }
+        const float scale = amp / 8388608.0f;
+        const uint64_t key = fnv1a64(name) ^ (seed * GOLD);
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < (long)n; i++) {
+            uint64_t z = key + (uint64_t)i * GOLD;
+            z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+            z ^= z >> 27; z *= 0x94D049BB133111EBull;
+            z ^= z >> 31;
+            float v = ((float)(uint32_t)(z >> 40) - 8388608.0f) * scale;
+            dst[i] = (offv != 0.0f) ? offv + v : v;
+        }
+    }
+}
+
+// ---- safetensors / config.json --------------------------------------------------------------
+static bool read_file(const std::string& path, std::string& out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::stringstream ss;
+    ss << f.rdbuf();
+    out = ss.str();
+    return true;
+}
+static float half_to_float(uint16_t h) {
+    uint32_t s = (h >> 15) & 1, e = (h >> 10) & 31, m = h & 1023, u;
+    if (e == 0) {
+        if (m == 0) u = s << 31;
+        else {
+            int sh = 0;
+            while (!(m & 1024)) { m <<= 1; sh++; }
+            m &= 1023;
+            u = (s << 31) | ((uint32_t)(127 - 15 - sh + 1) << 23) | (m << 13);
+        }
+    } else if (e == 31) u = (s << 31) | 0x7F800000u | (m << 13);
+    else u = (s << 31) | ((e + 112) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+int wh_load_model_dir(const std::string& dir, wh_dims* dims, std::vector<float>& master) {
+    std::string txt, err;
+    if (!read_file(dir + "/config.json", txt)) {
+        wh_set_error("onnx_dir does not hold a config.json: %s", dir.c_str());
+        return WH_ERR_IO;
+    }
+    auto cfg = whjson::parse(txt, &err);
+    if (!cfg || !cfg->is(whjson::Value::Obj)) {
+        wh_set_error("config.json: %s", err.c_str());
+        return WH_ERR_IO;
+    }
+    auto geti = [&](const char* k, int64_t dflt) {
+        auto v = cfg->get(k);
+        return v ? v->as_i64(dflt) : dflt;
+    };
+    dims->n_mels = (int)geti("num_mel_bins", 80);
+    dims->d_model = (int)geti("d_model", 0);
+    dims->n_heads = (int)geti("encoder_attention_heads", 0);
+    dims->enc_layers = (int)geti("encoder_layers", 0);
+    dims->dec_layers = (int)geti("decoder_layers", 0);
+    dims->ffn = (int)geti("encoder_ffn_dim", 0);
+    dims->vocab = (int)geti("vocab_size", 0);
+    dims->n_audio_ctx = (int)geti("max_source_positions", 1500);
+    dims->n_text_ctx = (int)geti("max_target_positions", 448);
+    if (geti("decoder_attention_heads", dims->n_heads) != dims->n_heads || geti("decoder_ffn_dim", dims->ffn) != dims->ffn) {
+        wh_set_error("config.json: encoder/decoder head count or ffn width differ (unsupported)");
+        return WH_ERR_UNSUPPORTED;
+    }
+    // safetensors: u64 header length, JSON header, raw little-endian data
+    const std::string st = dir + "/model.safetensors";
+    FILE* f = fopen(st.c_str(), "rb");
+    if (!f) {
+        wh_set_error("Failed to load %s", st.c_str());
+        return WH_ERR_IO;
+    }
+    uint64_t hlen = 0;
+    if (fread(&hlen, 8, 1, f) != 1 || hlen > (1ull << 30)) {
+        fclose(f);
+        wh_set_error("%s: bad safetensors header", st.c_str());
+        return WH_ERR_IO;
+    }
+    std::string hdr(hlen, '\0');
+    if (fread(&hdr[0], 1, hlen, f) != hlen) {
+        fclose(f);
+        wh_set_error("%s: truncated header", st.c_str());
+        return WH_ERR_IO;
+    }
+    auto h = whjson::parse(hdr, &err);
+    if (!h || !h->is(whjson::Value::Obj)) {
+        fclose(f);
+        wh_set_error("%s: header JSON: %s", st.c_str(), err.c_str());
+        return WH_ERR_IO;
+    }
+    TensorTable tt;
+    wh_tensor_table(*dims, tt);
+    size_t total = 0;
+    for (auto& e : tt) total += numel(e.second);
+    master.resize(total);
+    size_t off = 0;
+    std::vector<char> buf;
+    for (auto& e : tt) {
+        const size_t n = numel(e.second);
+        const whjson::Value* ent = h->get(e.first);
+        if (!ent && e.first.rfind("model.", 0) == 0) ent = h->get(e.first.substr(6));
+        if (!ent) {
+            fclose(f);
+            wh_set_error("%s: missing tensor %s", st.c_str(), e.first.c_str());
+            return WH_ERR_IO;
+        }
+        const whjson::Value* dt = ent->get("dtype");
+        const whjson::Value* sh = ent->get("shape");
+        const whjson::Value* offs = ent->get("data_offsets");
+        if (!dt || !sh || !offs || offs->arr.size() != 2) {
+            fclose(f);
+            wh_set_error("%s: malformed entry %s", st.c_str(), e.first.c_str());
+            return WH_ERR_IO;
+        }
+        size_t cnt = 1;
+        for (auto& s : sh->arr) cnt *= (size_t)s->as_i64();
+        if (cnt != n) {
+            fclose(f);
+            wh_set_error("%s: tensor %s has %zu elements, expected %zu", st.c_str(), e.first.c_str(), cnt, n);
+            return WH_ERR_BAD_SHAPE;
+        }
+        const int64_t b0 = offs->arr[0]->as_i64(), b1 = offs->arr[1]->as_i64();
+        const size_t esz = dt->str == "F32" ? 4 : (dt->str == "F16" || dt->str == "BF16") ? 2 : 0;
+        if (!esz || (size_t)(b1 - b0) != n * esz) {
+            fclose(f);
+            wh_set_error("%s: tensor %s dtype %s unsupported or size mismatch", st.c_str(), e.first.c_str(), dt->str.c_str());
+            return WH_ERR_UNSUPPORTED;
+        }
+        buf.resize(n * esz);
+        if (fseek(f, (long)(8 + hlen + b0), SEEK_SET) || fread(buf.data(), 1, buf.size(), f) != buf.size()) {
+            fclose(f);
+            wh_set_error("%s: short read for %s", st.c_str(), e.first.c_str());
+            return WH_ERR_IO;
+        }
+        float* dst = master.data() + off;
+        if (esz == 4) memcpy(dst, buf.data(), n * 4);
+        else {
+            const uint16_t* s16 = (const uint16_t*)buf.data();
+            if (dt->str == "BF16")
+                for (size_t i = 0; i < n; i++) { uint32_t u = (uint32_t)s16[i] << 16; memcpy(dst + i, &u, 4); }
+            else
+                for (size_t i = 0; i < n; i++) dst[i] = half_to_float(s16[i]);
+        }
+        off += n;
+    }
+    fclose(f);
+    return WH_OK;
+}
+
+// ---- device layout ----------------------------------------------------------------------------
+static inline uint16_t f32_to_bf16(float f) {  // round-to-nearest-even, NaN kept quiet
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+namespace {
+struct Stager {
+    std::vector<char> host;
+    size_t esz;
+    explicit Stager(size_t e) : esz(e) {}
+    size_t reserve(size_t bytes) {
+        size_t off = (host.size() + 255) & ~(size_t)255;
+        host.resize(off + bytes, 0);
+        return off;
+    }
+    // compute-dtype matrix from f32 rows: dst[r][c] for r<rows, c<cols_pad (zero beyond cols)
+    size_t put_mat(const float* src, size_t rows, size_t cols, size_t cols_pad, float scale = 1.0f) {
+        size_t off = reserve(rows * cols_pad * esz);
+        for (size_t r = 0; r < rows; r++) put_row(off, r, cols_pad, src + r * cols, cols, scale);
+        return off;
+    }
+    void put_row(size_t off, size_t r, size_t cols_pad, const float* src, size_t cols, float scale) {
+        if (esz == 4) {
+            float* d = (float*)(host.data() + off) + r * cols_pad;
+            for (size_t c = 0; c < cols; c++) d[c] = src[c] * scale;
+        } else {
+            uint16_t* d = (uint16_t*)(host.data() + off) + r * cols_pad;
+            for (size_t c = 0; c < cols; c++) d[c] = f32_to_bf16(src[c] * scale);
+        }
+    }
+    size_t put_f32(const float* src, size_t n, float scale = 1.0f) {
+        size_t off = reserve(n * 4);
+        float* d = (float*)(host.data() + off);
+        for (size_t i = 0; i < n; i++) d[i] = src ? src[i] * scale : 0.0f;
+        return off;
+    }
+};
+}  // namespace
+
+int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device, int precision, wh_model** out) {
+    if (precision != WH_PREC_F32 && precision != WH_PREC_BF16) {
+        wh_set_error("unsupported precision %d", precision);
+        return WH_ERR_UNSUPPORTED;
+    }
+    if (c.d_model <= 0 || c.n_heads <= 0 || c.d_model / c.n_heads != WH_HEAD_DIM || c.d_model % 128 || c.ffn % 128 ||
+        c.n_mels % 16 || c.d_model > 1280 || c.n_audio_ctx != 1500 || c.n_text_ctx > 512 || c.vocab <= 0) {
+        wh_set_error("unsupported model geometry (need head_dim 64, d_model %% 128 == 0, d_model <= 1280, n_mels %% 16 == 0, 1500 audio positions)");
+        return WH_ERR_UNSUPPORTED;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        wh_set_error("no HIP device available: libwhisper_hip has no CPU fallback");
+        return WH_ERR_HIP;
+    }
+    if (device < 0 || device >= ndev) {
+        wh_set_error("device %d out of range (%d devices)", device, ndev);
+        return WH_ERR_ARG;
+    }
+    WH_HIP_CHECK(hipSetDevice(device));
+    auto* m = new wh_model();
+    m->dims = c;
+    m->prec = precision;
+    m->device = device;
+    m->esz = precision == WH_PREC_F32 ? 4 : 2;
+    m->master = std::move(master_in);
+    TensorTable tt;
+    wh_tensor_table(c, tt);
+    size_t off = 0;
+    for (auto& e : tt) {
+        m->index[e.first] = {off, numel(e.second)};
+        off += numel(e.second);
+    }
+    if (off != m->master.size()) {
+        wh_set_error("weight blob has %zu floats, geometry needs %zu", m->master.size(), off);
+        delete m;
+        return WH_ERR_BAD_SHAPE;
+    }
+    auto T = [&](const std::string& n) -> const float* { return m->master.data() + m->index.at(n).first; };
+    const size_t d = c.d_model, F = c.ffn, C = c.n_mels;
+    const float qs = 1.0f / sqrtf((float)WH_HEAD_DIM);  // 0.125: exact, folded into W_q, b_q
+    Stager st(m->esz);
+    std::vector<float> tmp;
+
+    // conv weights tap-major: Wr[o][k*Cin + c] = W[o][c][k]
+    auto conv_reorder = [&](const float* w, size_t cout, size_t cin, size_t kpad) {
+        tmp.assign(cout * kpad, 0.0f);
+        for (size_t o = 0; o < cout; o++)
+            for (size_t ci = 0; ci < cin; ci++)
+                for (size_t k = 0; k < 3; k++) tmp[o * kpad + k * cin + ci] = w[(o * cin + ci) * 3 + k];
+        return st.put_mat(tmp.data(), cout, kpad, kpad);
+    };
+    m->conv1_k = (int)((3 * C + 31) / 32 * 32);
+    const std::string e = "model.encoder", dd = "model.decoder";
+    size_t o_conv1 = conv_reorder(T(e + ".conv1.weight"), d, C, m->conv1_k);
+    size_t o_conv1b = st.put_f32(T(e + ".conv1.bias"), d);
+    size_t o_conv2 = conv_reorder(T(e + ".conv2.weight"), d, d, 3 * d);
+    size_t o_conv2b = st.put_f32(T(e + ".conv2.bias"), d);
+    size_t o_encpos = st.put_f32(T(e + ".embed_positions.weight"), (size_t)c.n_audio_ctx * d);
+    struct EncOff { size_t qk, qkb, v, vb, o, ob, f1, f1b, f2, f2b, l1w, l1b, l2w, l2b; };
+    std::vector<EncOff> eo(c.enc_layers);
+    for (int i = 0; i < c.enc_layers; i++) {
+        std::string p = e + ".layers." + std::to_string(i);
+        EncOff& x = eo[i];
+        x.qk = st.reserve(2 * d * d * m->esz);
+        for (size_t r = 0; r < d; r++) {
+            st.put_row(x.qk, r, d, T(p + ".self_attn.q_proj.weight") + r * d, d, qs);
+            st.put_row(x.qk, d + r, d, T(p + ".self_attn.k_proj.weight") + r * d, d, 1.0f);
+        }
+        tmp.assign(2 * d, 0.0f);
+        for (size_t r = 0; r < d; r++) tmp[r] = T(p + ".self_attn.q_proj.bias")[r] * qs;
+        x.qkb = st.put_f32(tmp.data(), 2 * d);
+        x.v = st.put_mat(T(p + ".self_attn.v_proj.weight"), d, d, d);
+        x.vb = st.put_f32(T(p + ".self_attn.v_proj.bias"), d);
+        x.o = st.put_mat(T(p + ".self_attn.out_proj.weight"), d, d, d);
+        x.ob = st.put_f32(T(p + ".self_attn.out_proj.bias"), d);
+        x.f1 = st.put_mat(T(p + ".fc1.weight"), F, d, d);
+        x.f1b = st.put_f32(T(p + ".fc1.bias"), F);
+        x.f2 = st.put_mat(T(p + ".fc2.weight"), d, F, F);
+        x.f2b = st.put_f32(T(p + ".fc2.bias"), d);
+        x.l1w = st.put_f32(T(p + ".self_attn_layer_norm.weight"), d);
+        x.l1b = st.put_f32(T(p + ".self_attn_layer_norm.bias"), d);
+        x.l2w = st.put_f32(T(p + ".final_layer_norm.weight"), d);
+        x.l2b = st.put_f32(T(p + ".final_layer_norm.bias"), d);
+    }
+    size_t o_elnw = st.put_f32(T(e + ".layer_norm.weight"), d), o_elnb = st.put_f32(T(e + ".layer_norm.bias"), d);
+    size_t o_tok = st.put_mat(T(dd + ".embed_tokens.weight"), c.vocab, d, d);
+    size_t o_dpos = st.put_f32(T(dd + ".embed_positions.weight"), (size_t)c.n_text_ctx * d);
+    struct DecOff { size_t qkv, qkvb, o, ob, cq, cqb, co, cob, f1, f1b, f2, f2b, l1w, l1b, l2w, l2b, l3w, l3b; };
+    std::vector<DecOff> dof(c.dec_layers);
+    const size_t Ld = c.dec_layers;
+    size_t o_ckv = st.reserve(Ld * 2 * d * d * m->esz);
+    tmp.assign(Ld * 2 * d, 0.0f);
+    std::vector<float> ckvb(Ld * 2 * d, 0.0f);
+    for (int i = 0; i < c.dec_layers; i++) {
+        std::string p = dd + ".layers." + std::to_string(i);
+        DecOff& x = dof[i];
+        x.qkv = st.reserve(3 * d * d * m->esz);
+        for (size_t r = 0; r < d; r++) {
+            st.put_row(x.qkv, r, d, T(p + ".self_attn.q_proj.weight") + r * d, d, qs);
+            st.put_row(x.qkv, d + r, d, T(p + ".self_attn.k_proj.weight") + r * d, d, 1.0f);
+            st.put_row(x.qkv, 2 * d + r, d, T(p + ".self_attn.v_proj.weight") + r * d, d, 1.0f);
+        }
+        std::vector<float> b3(3 * d, 0.0f);
+        for (size_t r = 0; r < d; r++) {
+            b3[r] = T(p + ".self_attn.q_proj.bias")[r] * qs;
+            b3[2 * d + r] = T(p + ".self_attn.v_proj.bias")[r];
+        }
+        x.qkvb = st.put_f32(b3.data(), 3 * d);
+        x.o = st.put_mat(T(p + ".self_attn.out_proj.weight"), d, d, d);
+        x.ob = st.put_f32(T(p + ".self_attn.out_proj.bias"), d);
+        x.cq = st.put_mat(T(p + ".encoder_attn.q_proj.weight"), d, d, d, qs);
+        x.cqb = st.put_f32(T(p + ".encoder_attn.q_proj.bias"), d, qs);
+        x.co = st.put_mat(T(p + ".encoder_attn.out_proj.weight"), d, d, d);
+        x.cob = st.put_f32(T(p + ".encoder_attn.out_proj.bias"), d);
+        for (size_t r = 0; r < d; r++) {
+            st.put_row(o_ckv, ((size_t)i * 2 + 0) * d + r, d, T(p + ".encoder_attn.k_proj.weight") + r * d, d, 1.0f);
+            st.put_row(o_ckv, ((size_t)i * 2 + 1) * d + r, d, T(p + ".encoder_attn.v_proj.weight") + r * d, d, 1.0f);
+            ckvb[((size_t)i * 2 + 1) * d + r] = T(p + ".encoder_attn.v_proj.bias")[r];
+        }
+        x.f1 = st.put_mat(T(p + ".fc1.weight"), F, d, d);
+        x.f1b = st.put_f32(T(p + ".fc1.bias"), F);
+        x.f2 = st.put_mat(T(p + ".fc2.weight"), d, F, F);
+        x.f2b = st.put_f32(T(p + ".fc2.bias"), d);
+        x.l1w = st.put_f32(T(p + ".self_attn_layer_norm.weight"), d);
+        x.l1b = st.put_f32(T(p + ".self_attn_layer_norm.bias"), d);
+        x.l2w = st.put_f32(T(p + ".encoder_attn_layer_norm.weight"), d);
+        x.l2b = st.put_f32(T(p + ".encoder_attn_layer_norm.bias"), d);
+        x.l3w = st.put_f32(T(p + ".final_layer_norm.weight"), d);
+        x.l3b = st.put_f32(T(p + ".final_layer_norm.bias"), d);
+    }
+    size_t o_ckvb = st.put_f32(ckvb.data(), ckvb.size());
+    size_t o_dlnw = st.put_f32(T(dd + ".layer_norm.weight"), d), o_dlnb = st.put_f32(T(dd + ".layer_norm.bias"), d);
+    // log-mel tables
+    std::vector<double> tw;
+    std::vector<float> win, fbT;
+    wh_build_mel_tables(c.n_mels, tw, win, fbT);
+    size_t o_tw = st.reserve(tw.size() * 8);
+    memcpy(st.host.data() + o_tw, tw.data(), tw.size() * 8);
+    size_t o_win = st.put_f32(win.data(), win.size());
+    size_t o_fb = st.put_f32(fbT.data(), fbT.size());
+    st.reserve(4096);  // slack: conv1's K padding may read a few elements past a matrix
+
+    m->arena_bytes = st.host.size();
+    hipError_t he = hipMalloc((void**)&m->arena, m->arena_bytes);
+    if (he != hipSuccess) {
+        delete m;
+        return wh_fail_hip(he, "hipMalloc(weights)", __FILE__, __LINE__);
+    }
+    he = hipMemcpy(m->arena, st.host.data(), m->arena_bytes, hipMemcpyHostToDevice);
+    if (he != hipSuccess) {
+        hipFree(m->arena);
+        delete m;
+        return wh_fail_hip(he, "hipMemcpy(weights)", __FILE__, __LINE__);
+    }
+    auto P = [&](size_t o) { return (void*)(m->arena + o); };
+    auto PF = [&](size_t o) { return (float*)(m->arena + o); };
+    m->conv1_w = P(o_conv1); m->conv1_b = PF(o_conv1b);
+    m->conv2_w = P(o_conv2); m->conv2_b = PF(o_conv2b);
+    m->enc_pos = PF(o_encpos);
+    m->enc.resize(c.enc_layers);
+    for (int i = 0; i < c.enc_layers; i++) {
+        EncOff& x = eo[i];
+        m->enc[i] = EncLayerDev{P(x.qk), P(x.v), P(x.o), P(x.f1), P(x.f2), PF(x.qkb), PF(x.vb), PF(x.ob), PF(x.f1b),
+                                PF(x.f2b), PF(x.l1w), PF(x.l1b), PF(x.l2w), PF(x.l2b)};
+    }
+    m->enc_ln_w = PF(o_elnw); m->enc_ln_b = PF(o_elnb);
+    m->tok_emb = P(o_tok); m->dec_pos = PF(o_dpos);
+    m->dec.resize(c.dec_layers);
+    for (int i = 0; i < c.dec_layers; i++) {
+        DecOff& x = dof[i];
+        m->dec[i] = DecLayerDev{P(x.qkv), P(x.o), P(x.cq), P(x.co), P(x.f1), P(x.f2), PF(x.qkvb), PF(x.ob), PF(x.cqb),
+                                PF(x.cob), PF(x.f1b), PF(x.f2b), PF(x.l1w), PF(x.l1b), PF(x.l2w), PF(x.l2b), PF(x.l3w),
+                                PF(x.l3b)};
+    }
+    m->cross_kv_w = P(o_ckv); m->cross_kv_b = PF(o_ckvb);
+    m->dec_ln_w = PF(o_dlnw); m->dec_ln_b = PF(o_dlnb);
+    m->mel_tw = (double*)P(o_tw); m->mel_win = PF(o_win); m->mel_fbT = PF(o_fb);
+    *out = m;
+    return WH_OK;
+}
