@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X-native Whisper hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[2] scaled to the GPUs present; at N=1 it is configs[1]'s model
+and dtype on one GPU's share of the clip set): whisper-base dims, bf16 MFMA, hash-seeded synthetic
+weights, synthetic 30 s clips (modelspec.synth_clip), greedy decode of exactly 128 new tokens per
+clip (EOT placed in suppress_tokens — the reference's own mechanism, src/main.rs:765,817), clips
+sharded across ranks with no data-path collective; one STEP = one pass of
+log-mel → encoder → cross-KV → 128-token greedy decode over one batch of `--clips` clips per GPU,
+PCM already resident in HBM.
+
+Prints ONE JSON line (rank 0).  `value` = audio seconds transcribed per wall second by the whole
+job (the "× real time" figure of BASELINE.json, rtfx = 1/rtf with rtf = src/main.rs:1191).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from whisper_rust_ort_amd import binding as wb  # noqa: E402
+from whisper_rust_ort_amd import modelspec as ms  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA
+MFMA_F32_PEAK_TF = 157.3
+
+
+class Hip:
+    """Just enough of the HIP runtime (the instance libwhisper_hip.so already loaded) to keep the
+    benchmark's PCM resident in HBM."""
+
+    def __init__(self):
+        self.lib = C.CDLL("libamdhip64.so.7", mode=C.RTLD_GLOBAL)
+        self.lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.lib.hipFree.argtypes = [C.c_void_p]
+        self.lib.hipSetDevice.argtypes = [C.c_int]
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed with hipError {rc}")
+
+    def upload(self, dev: int, arr: np.ndarray) -> int:
+        self.check(self.lib.hipSetDevice(dev), "hipSetDevice")
+        p = C.c_void_p()
+        self.check(self.lib.hipMalloc(C.byref(p), arr.nbytes), "hipMalloc")
+        self.check(self.lib.hipMemcpy(p, arr.ctypes.data_as(C.c_void_p), arr.nbytes, 1), "hipMemcpy H2D")
+        self.check(self.lib.hipDeviceSynchronize(), "hipDeviceSynchronize")
+        return p.value
+
+    def sync(self):
+        self.check(self.lib.hipDeviceSynchronize(), "hipDeviceSynchronize")
+
+
+def algorithmic_work(dims, n_clips: int, n_prompt: int, max_new: int, esz: int) -> dict:
+    """SURVEY.md §8d formulas, per launch / per batch."""
+    d, F, T, Ld, Le, V, M = dims.d_model, dims.ffn, dims.n_audio_ctx, dims.dec_layers, dims.enc_layers, dims.vocab, dims.n_mels
+    enc_flop = 2 * d * M * 3 * 3000 + 2 * d * d * 3 * T + Le * (2 * 4 * T * d * d + 2 * 2 * T * T * d + 2 * 2 * T * d * F)
+    cross_kv_flop = 2 * Ld * 2 * T * d * d
+    positions = n_prompt + max_new - 1
+    per_pos = Ld * 2 * (6 * d * d + 2 * d * F + 2 * T * d)
+    dec_flop = positions * per_pos + max_new * 2 * d * V
+    return {
+        "enc_flop_per_clip": enc_flop,
+        "cross_kv_flop_per_clip": cross_kv_flop,
+        "dec_flop_per_clip": dec_flop,
+        # one cross-attention launch reads K and V of one layer for every clip of the batch, once
+        "cross_attn_bytes_per_launch": 2 * T * d * esz * n_clips,
+        "cross_attn_launches": positions * Ld,
+        "mel_bytes_per_clip": 480000 * 4 + M * 3000 * 4,
+    }
+
+
+def cpu_baseline(dims, seed: int, prompt, eot, max_new: int) -> dict:
+    """The oracle (a port of the reference's algorithm — the Rust/ORT binary cannot be built here)
+    timed on this box's host cores for ONE clip of the same workload."""
+    from oracle import oracle as orc
+    w = ms.flatten_state_dict(dims, ms.synth_state_dict(dims, seed))
+    pcm = ms.synth_clip(0)
+    t0 = time.perf_counter()
+    mel = orc.log_mel(pcm, dims.n_mels)
+    t1 = time.perf_counter()
+    enc = orc.encoder(dims, w, mel)
+    t2 = time.perf_counter()
+    toks, _ = orc.decode_greedy(dims, w, enc, prompt, max_new, eot, suppress=[eot])
+    t3 = time.perf_counter()
+    return {"value": 30.0 / (t3 - t0), "unit": "x real time (audio s / wall s)", "cores": orc.num_threads(),
+            "kind": "port",
+            "sample": f"1 clip (30 s), whisper-base fp32, {max_new} new tokens, OpenMP C oracle; "
+                      f"mel {t1 - t0:.3f}s enc {t2 - t1:.3f}s dec {t3 - t2:.3f}s",
+            "seconds": t3 - t0, "tokens": [int(t) for t in toks[:8]]}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--clips", type=int, default=64, help="clips per GPU per step (batch resident in HBM)")
+    ap.add_argument("--preset", default="base")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--max-new-tokens", type=int, default=128)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="event-time every kernel group in the timed region")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    dist = None
+    backend = "none"
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL on ROCm
+            backend = "nccl"
+        except Exception:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            backend = "gloo"
+
+    dims = ms.PRESETS[a.preset]
+    prec = wb.WH_PREC_BF16 if a.precision == "bf16" else wb.WH_PREC_F32
+    esz = 2 if prec == wb.WH_PREC_BF16 else 4
+    if wb.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: libwhisper_hip has no CPU fallback")
+    dev = local_rank
+    model = wb.Model(f"synthetic:{a.preset}:{a.seed}", dev, prec)
+    ctx = wb.Context(model, a.clips)
+    hip = Hip()
+
+    # this rank's shard of the clip set: clip ids rank*clips .. (rank+1)*clips-1 (weak scaling)
+    pcm = np.stack([ms.synth_clip(rank * a.clips + i) for i in range(a.clips)])
+    d_pcm = hip.upload(dev, pcm)
+    if dims.vocab > 50400:
+        prompt, eot = [50258, 50259, 50359, 50363], 50257  # reference src/main.rs:549-566
+    else:
+        prompt, eot = [3, 5, 7, 9], 2
+    params = wb.DecodeParams(prompt, a.max_new_tokens, eot, suppress_tokens=[eot])
+
+    def barrier():
+        hip.sync()
+        if dist is not None:
+            dist.barrier()
+
+    # untimed: warmup + one fully profiled pass to find the dominant kernel group
+    toks = None
+    for _ in range(max(1, a.warmup)):
+        toks = ctx.transcribe_batch_device(d_pcm, a.clips, params)
+    assert all(len(t) == len(prompt) + a.max_new_tokens for t in toks), "EOT suppressed: every clip decodes max_new tokens"
+    ctx.profile_enable(True)
+    ctx.transcribe_batch_device(d_pcm, a.clips, params)
+    breakdown = ctx.profile_get()
+    ctx.profile_enable(bool(a.profile_all))
+
+    # timed region: EXACTLY K steps
+    lat = []
+    stage = {"preprocess_s": 0.0, "encode_s": 0.0, "decode_s": 0.0}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ts = time.perf_counter()
+        toks = ctx.transcribe_batch_device(d_pcm, a.clips, params)   # returns after the last D2H of the step
+        lat.append(time.perf_counter() - ts)
+        tm = ctx.timings()
+        for k in stage:
+            stage[k] += tm[k]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # the path's only exchange: fixed-stride result records gathered to every rank
+        rec = torch.zeros((a.clips, 2 + len(prompt) + a.max_new_tokens), dtype=torch.int32)
+        for i, tk in enumerate(toks):
+            rec[i, 0] = rank * a.clips + i
+            rec[i, 1] = len(tk)
+            rec[i, 2:2 + len(tk)] = torch.from_numpy(tk.astype(np.int32))
+        rec = rec.cuda() if backend == "nccl" else rec
+        out = [torch.zeros_like(rec) for _ in range(world)]
+        dist.all_gather(out, rec)
+        n_results = sum(int((o[:, 1] > 0).sum()) for o in out)
+    else:
+        n_results = len(toks)
+
+    if rank == 0:
+        work = algorithmic_work(dims, a.clips, len(prompt), a.max_new_tokens, esz)
+        audio_s = 30.0 * a.clips * a.steps * world
+        ms_per_step = elapsed / a.steps * 1e3
+        # roofline of the dominant kernel group (profiled pass over one identical step)
+        dom = max(breakdown, key=lambda k: breakdown[k]["ms"])
+        tot_ms = sum(v["ms"] for v in breakdown.values())
+        ca = breakdown["dec_cross_attn"]
+        roofline = None
+        if dom == "dec_cross_attn" and ca["launches"]:
+            avg_s = ca["ms"] * 1e-3 / ca["launches"]
+            ach = work["cross_attn_bytes_per_launch"] / avg_s / 1e9
+            roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                        "traffic": None, "kernel": "k_dec_cross_attn", "avg_launch_us": avg_s * 1e6,
+                        "launches": ca["launches"], "alg_bytes_per_launch": work["cross_attn_bytes_per_launch"]}
+        else:
+            flop = {"enc_gemm": (work["enc_flop_per_clip"] - dims.enc_layers * 4 * dims.n_audio_ctx ** 2 * dims.d_model) * a.clips,
+                    "enc_attn": dims.enc_layers * 4 * dims.n_audio_ctx ** 2 * dims.d_model * a.clips,
+                    "dec_gemm": (work["cross_kv_flop_per_clip"] + work["dec_flop_per_clip"]) * a.clips}.get(dom)
+            peak = MFMA_BF16_PEAK_TF if prec == wb.WH_PREC_BF16 else MFMA_F32_PEAK_TF
+            if flop:
+                ach = flop / (breakdown[dom]["ms"] * 1e-3) / 1e12
+                roofline = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                            "traffic": None, "kernel": dom, "launches": breakdown[dom]["launches"],
+                            "group_ms": breakdown[dom]["ms"], "alg_flop_per_step": flop}
+        out = {
+            "metric": "rtfx: audio seconds transcribed per wall second (whisper-base, 30 s clips, greedy 128 new tokens)",
+            "value": audio_s / elapsed, "unit": "x real time", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": f"whisper-{a.preset} dims, hash-seeded weights, {a.clips} synthetic 30 s clips per GPU per step "
+                                   f"(BASELINE configs[2] shard; model/dtype of configs[1]), greedy, max_new_tokens={a.max_new_tokens}, "
+                                   f"EOT suppressed, PCM resident in HBM", "clips_per_gpu": a.clips, "parallelism": f"clip-sharded x{world}",
+                       "gather": backend, "results_gathered": n_results},
+            "rtf": elapsed / audio_s,   # reference definition: latency / duration (src/main.rs:1191)
+            "clips_per_s": a.clips * a.steps * world / elapsed,
+            "p95_ms_per_clip": float(np.percentile(np.asarray(lat) * 1e3, 95)),  # every clip of a batch completes with its batch
+            "stage_ms_per_step": {k: v / a.steps * 1e3 for k, v in stage.items()},
+            "kernel_group_ms_per_step": {k: round(v["ms"], 3) for k, v in breakdown.items()},
+            "kernel_group_launches": {k: v["launches"] for k, v in breakdown.items()},
+            "kernel_time_frac_of_step": tot_ms / ms_per_step,
+            "roofline": roofline,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dims, a.seed, prompt, eot, a.max_new_tokens)
+            out["cpu_baseline"]["note"] = ("the reference's Rust/ONNX Runtime binary cannot be built or run here (no Rust, "
+                                           "no ORT, no network); published: 14.03 s model time for 12 windows on 4 EPYC-9654 cores")
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -31,11 +31,34 @@ def build(force: bool = False) -> str:
 _lib: Optional[C.CDLL] = None
 
 
+def cpu_budget(cap: int = 16) -> int:
+    """Usable host cores: min(affinity mask, cgroup CPU quota, cap).  The GPU box exposes every
+    hardware thread of the host but only grants a share of them; an OpenMP team sized to the
+    hardware count would oversubscribe that share by an order of magnitude."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, min(n, cap))
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         if not os.path.exists(_SO):
             build()
+        os.environ.setdefault("OMP_NUM_THREADS", str(cpu_budget()))
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
         L = C.CDLL(_SO)
         f32p, i64p = C.POINTER(C.c_float), C.POINTER(C.c_int64)
         L.orc_mel_frames.restype = C.c_size_t
@@ -51,6 +74,8 @@ def lib() -> C.CDLL:
                                         C.c_int64, i64p, C.c_size_t, i64p, C.c_size_t, i64p, C.c_size_t,
                                         i64p, C.POINTER(C.c_size_t), f32p]
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_set_threads(int(os.environ["OMP_NUM_THREADS"]))
         _lib = L
     return _lib
 

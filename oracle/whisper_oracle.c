@@ -646,6 +646,14 @@ int orc_decode_greedy(const orc_dims* c, const float* w, const float* enc /* [T]
     return ORC_OK;
 }
 
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

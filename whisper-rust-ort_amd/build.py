@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libwhisper_hip.so")
 SOURCES = ["wh_mel.hip", "wh_gemm.hip", "wh_attn.hip", "wh_decode.hip", "wh_model.cpp", "wh_api.cpp"]
 HEADERS = ["wh_common.h", "wh_kernels.h", "wh_internal.h", "wh_json.h", "../../include/whisper_hip.h"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fopenmp", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-pthread", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
          "-x", "hip"]
 
 
@@ -41,7 +41,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     if force or _stale(OUT, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fopenmp", "-o", OUT] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", OUT] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -15,8 +15,10 @@
 #include <string.h>
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <fstream>
 #include <sstream>
+#include <thread>
 
 #include "wh_common.h"
 #include "wh_internal.h"
@@ -151,14 +153,23 @@ void wh_synth_weights(const wh_dims& c, uint64_t seed, std::vector<float>& out) 
         }
         const float scale = amp / 8388608.0f;
         const uint64_t key = fnv1a64(name) ^ (seed * GOLD);
-#pragma omp parallel for schedule(static)
-        for (long i = 0; i < (long)n; i++) {
-            uint64_t z = key + (uint64_t)i * GOLD;
-            z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
-            z ^= z >> 27; z *= 0x94D049BB133111EBull;
-            z ^= z >> 31;
-            float v = ((float)(uint32_t)(z >> 40) - 8388608.0f) * scale;
-            dst[i] = (offv != 0.0f) ? offv + v : v;
+        auto fill = [=](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++) {
+                uint64_t z = key + (uint64_t)i * GOLD;
+                z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+                z ^= z >> 27; z *= 0x94D049BB133111EBull;
+                z ^= z >> 31;
+                float v = ((float)(uint32_t)(z >> 40) - 8388608.0f) * scale;
+                dst[i] = (offv != 0.0f) ? offv + v : v;
+            }
+        };
+        const size_t nthr = n > (1u << 20) ? 8 : 1;
+        if (nthr == 1) fill(0, n);
+        else {
+            std::vector<std::thread> th;
+            const size_t per = (n + nthr - 1) / nthr;
+            for (size_t t = 0; t < nthr; t++) th.emplace_back(fill, std::min(n, t * per), std::min(n, (t + 1) * per));
+            for (auto& t : th) t.join();
         }
     }
 }
