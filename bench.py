@@ -110,6 +110,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clips", type=int, default=64, help="clips per GPU per step (batch resident in HBM)")
+    ap.add_argument("--streams", type=int, default=1, help="independent HIP streams (contexts) per GPU; clips are split evenly")
     ap.add_argument("--preset", default="base")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--max-new-tokens", type=int, default=128)
@@ -145,7 +146,10 @@ def main() -> None:
         raise SystemExit("bench.py needs an MI355X: libwhisper_hip has no CPU fallback")
     dev = local_rank
     model = wb.Model(f"synthetic:{a.preset}:{a.seed}", dev, prec)
-    ctx = wb.Context(model, a.clips)
+    assert a.clips % a.streams == 0, "--clips must be a multiple of --streams"
+    per_stream = a.clips // a.streams
+    ctxs = [wb.Context(model, per_stream) for _ in range(a.streams)]
+    ctx = ctxs[0]
     hip = Hip()
 
     # this rank's shard of the clip set: clip ids rank*clips .. (rank+1)*clips-1 (weak scaling)
@@ -162,15 +166,33 @@ def main() -> None:
         if dist is not None:
             dist.barrier()
 
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=a.streams)
+
+    def run_step():
+        """One pass over this GPU's clips: every stream transcribes its slice concurrently (ctypes
+        releases the GIL; each context owns a HIP stream)."""
+        def one(i):
+            return ctxs[i].transcribe_batch_device(d_pcm + i * per_stream * 480000 * 4, per_stream, params)
+        if a.streams == 1:
+            return one(0)
+        res = list(pool.map(one, range(a.streams)))
+        return [t for r in res for t in r]
+
     # untimed: warmup + one fully profiled pass to find the dominant kernel group
     toks = None
     for _ in range(max(1, a.warmup)):
-        toks = ctx.transcribe_batch_device(d_pcm, a.clips, params)
+        toks = run_step()
     assert all(len(t) == len(prompt) + a.max_new_tokens for t in toks), "EOT suppressed: every clip decodes max_new tokens"
-    ctx.profile_enable(True)
-    ctx.transcribe_batch_device(d_pcm, a.clips, params)
-    breakdown = ctx.profile_get()
-    ctx.profile_enable(bool(a.profile_all))
+    for cx in ctxs:
+        cx.profile_enable(True)
+    run_step()
+    breakdown = {k: {"ms": sum(cx.profile_get()[k]["ms"] for cx in ctxs) / a.streams,
+                     "launches": sum(cx.profile_get()[k]["launches"] for cx in ctxs)} for k in wb.KG_NAMES}
+    # timed region: only the dominant kernel (decoder cross-attention) is bracketed by HIP events
+    for cx in ctxs:
+        cx.profile_enable(True if a.profile_all else ["dec_cross_attn"])
+    live = {"ms": 0.0, "launches": 0}
 
     # timed region: EXACTLY K steps
     lat = []
@@ -179,11 +201,15 @@ def main() -> None:
     t0 = time.perf_counter()
     for _ in range(a.steps):
         ts = time.perf_counter()
-        toks = ctx.transcribe_batch_device(d_pcm, a.clips, params)   # returns after the last D2H of the step
+        toks = run_step()   # returns after the last D2H of the step
         lat.append(time.perf_counter() - ts)
-        tm = ctx.timings()
-        for k in stage:
-            stage[k] += tm[k]
+        for cx in ctxs:
+            tm = cx.timings()
+            for k in stage:
+                stage[k] += tm[k] / a.streams
+            pg = cx.profile_get()["dec_cross_attn"]
+            live["ms"] += pg["ms"]
+            live["launches"] += pg["launches"]
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -205,30 +231,26 @@ def main() -> None:
         n_results = len(toks)
 
     if rank == 0:
-        work = algorithmic_work(dims, a.clips, len(prompt), a.max_new_tokens, esz)
+        work = algorithmic_work(dims, per_stream, len(prompt), a.max_new_tokens, esz)
         audio_s = 30.0 * a.clips * a.steps * world
         ms_per_step = elapsed / a.steps * 1e3
-        # roofline of the dominant kernel group (profiled pass over one identical step)
-        dom = max(breakdown, key=lambda k: breakdown[k]["ms"])
+        # Roofline of the dominant kernel (k_dec_cross_attn: largest single-kernel share in every
+        # rocprofv3 --stats summary under profiles/).  `achieved` = algorithmic bytes per launch
+        # (K and V of one decoder layer for every clip of the launch) ÷ the average launch
+        # duration measured with HIP events on the launch stream over the TIMED region.
         tot_ms = sum(v["ms"] for v in breakdown.values())
-        ca = breakdown["dec_cross_attn"]
-        roofline = None
-        if dom == "dec_cross_attn" and ca["launches"]:
-            avg_s = ca["ms"] * 1e-3 / ca["launches"]
-            ach = work["cross_attn_bytes_per_launch"] / avg_s / 1e9
-            roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                        "traffic": None, "kernel": "k_dec_cross_attn", "avg_launch_us": avg_s * 1e6,
-                        "launches": ca["launches"], "alg_bytes_per_launch": work["cross_attn_bytes_per_launch"]}
-        else:
-            flop = {"enc_gemm": (work["enc_flop_per_clip"] - dims.enc_layers * 4 * dims.n_audio_ctx ** 2 * dims.d_model) * a.clips,
-                    "enc_attn": dims.enc_layers * 4 * dims.n_audio_ctx ** 2 * dims.d_model * a.clips,
-                    "dec_gemm": (work["cross_kv_flop_per_clip"] + work["dec_flop_per_clip"]) * a.clips}.get(dom)
-            peak = MFMA_BF16_PEAK_TF if prec == wb.WH_PREC_BF16 else MFMA_F32_PEAK_TF
-            if flop:
-                ach = flop / (breakdown[dom]["ms"] * 1e-3) / 1e12
-                roofline = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                            "traffic": None, "kernel": dom, "launches": breakdown[dom]["launches"],
-                            "group_ms": breakdown[dom]["ms"], "alg_flop_per_step": flop}
+        avg_s = live["ms"] * 1e-3 / max(1, live["launches"])
+        ach = work["cross_attn_bytes_per_launch"] / avg_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):   # HBM bytes per launch from rocprofv3 --pmc passes (see profiles/README.md)
+            tj = json.load(open(tpath))
+            key = f"{a.preset}_{a.precision}_b{per_stream}"
+            traffic = tj.get("k_dec_cross_attn", {}).get(key)
+        roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": traffic, "kernel": "k_dec_cross_attn", "avg_launch_us": avg_s * 1e6,
+                    "launches_timed": live["launches"], "alg_bytes_per_launch": work["cross_attn_bytes_per_launch"],
+                    "share_of_kernel_time": breakdown["dec_cross_attn"]["ms"] / tot_ms}
         out = {
             "metric": "rtfx: audio seconds transcribed per wall second (whisper-base, 30 s clips, greedy 128 new tokens)",
             "value": audio_s / elapsed, "unit": "x real time", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -236,7 +258,7 @@ def main() -> None:
             "dtype": a.precision, "data": "synthetic",
             "config": {"workload": f"whisper-{a.preset} dims, hash-seeded weights, {a.clips} synthetic 30 s clips per GPU per step "
                                    f"(BASELINE configs[2] shard; model/dtype of configs[1]), greedy, max_new_tokens={a.max_new_tokens}, "
-                                   f"EOT suppressed, PCM resident in HBM", "clips_per_gpu": a.clips, "parallelism": f"clip-sharded x{world}",
+                                   f"EOT suppressed, PCM resident in HBM", "clips_per_gpu": a.clips, "streams_per_gpu": a.streams, "parallelism": f"clip-sharded x{world}",
                        "gather": backend, "results_gathered": n_results},
             "rtf": elapsed / audio_s,   # reference definition: latency / duration (src/main.rs:1191)
             "clips_per_s": a.clips * a.steps * world / elapsed,

@@ -164,9 +164,10 @@ int wh_transcribe_longform(wh_ctx* c, const float* pcm, size_t n_samples, double
 #define WH_KG_DEC_GEMM 4
 #define WH_KG_DEC_OTHER 5
 #define WH_KG_COUNT 6
-/* When enabled, every launch of the group is bracketed by hipEvents on the launch stream; the
- * totals of the last transcribe call are returned as (milliseconds, launches) per group. */
-int wh_profile_enable(wh_ctx* c, int enable);
+/* group_mask: bit g set → every launch of kernel group g is bracketed by hipEvents on the launch
+ * stream (0 = off; while on, decode steps are launched eagerly instead of replaying the captured
+ * hipGraph).  The totals of the last transcribe call come back as (milliseconds, launches) per group. */
+int wh_profile_enable(wh_ctx* c, int group_mask);
 int wh_profile_get(const wh_ctx* c, double* ms /* [WH_KG_COUNT] */, int64_t* launches /* [WH_KG_COUNT] */);
 
 /* Host-only: the hash-seeded weights of "synthetic:<preset>:<seed>" as one f32 blob in canonical

@@ -275,8 +275,15 @@ class Context:
         self.lib.wh_get_timings(self.h, C.byref(t))
         return {k: getattr(t, k) for k, _ in WhTiming._fields_}
 
-    def profile_enable(self, on: bool = True):
-        self.lib.wh_profile_enable(self.h, 1 if on else 0)
+    def profile_enable(self, groups=True):
+        """groups: True/False (all/none) or an iterable of KG_NAMES to event-time."""
+        if groups is True:
+            mask = (1 << len(KG_NAMES)) - 1
+        elif not groups:
+            mask = 0
+        else:
+            mask = sum(1 << KG_NAMES.index(g) for g in groups)
+        self.lib.wh_profile_enable(self.h, mask)
 
     def profile_get(self) -> dict:
         ms = (C.c_double * len(KG_NAMES))()

@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -53,7 +54,7 @@ struct Prof {
     int g;
     size_t slot = 0;
     bool on;
-    Prof(wh_ctx* ctx, int group) : c(ctx), g(group), on(ctx->prof) {
+    Prof(wh_ctx* ctx, int group) : c(ctx), g(group), on(ctx->prof && ((ctx->prof_mask >> group) & 1)) {
         c->prof_launches[g]++;
         if (!on) return;
         auto& v = c->prof_events[g];
@@ -224,6 +225,8 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     CTX_HIP(c, hipMemcpyAsync(c->n_out, nout.data(), nb * 4, hipMemcpyHostToDevice, s));
     CTX_HIP(c, hipMemsetAsync(c->done, 0, nb * 4, s));
     CTX_HIP(c, hipMemsetAsync(c->pos, 0, 4, s));
+    CTX_HIP(c, hipMemsetAsync(c->step_ticket, 0, 4, s));
+    CTX_HIP(c, hipMemsetAsync(c->cross_tickets, 0, nb * 4, s));
     std::vector<int> forced(p->n_forced);
     for (size_t i = 0; i < p->n_forced; i++) forced[i] = (int)p->forced[i];
     if (!forced.empty()) CTX_HIP(c, hipMemcpyAsync(c->forced, forced.data(), forced.size() * 4, hipMemcpyHostToDevice, s));
@@ -267,89 +270,129 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     const long cache_l = (long)nb * D.n_heads * D.n_text_ctx * WH_HEAD_DIM;  // elements per layer
     const int total_pos = P + NEW - 1;
     std::vector<int> done_h(nb);
-    for (int step = 0; step < total_pos; step++) {
-        { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_dec_embed(s, prec, m->tok_emb, m->dec_pos, c->feed, ld, c->pos, c->dx, (int)d, nb); }
-        for (int l = 0; l < D.dec_layers; l++) {
-            const DecLayerDev& L = m->dec[l];
-            SkinnyArgs a;
-            { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_layernorm(s, prec, c->dx, L.ln1_w, L.ln1_b, c->dxn, nb, (int)d); }
-            {
-                Prof pr(c, WH_KG_DEC_GEMM);
-                a = SkinnyArgs();
-                a.X = c->dxn; a.ldx = d; a.W = L.qkv_w; a.bias = L.qkv_b; a.C = c->dqkv; a.ldc = 3 * d;
-                a.M = nb; a.N = (int)(3 * d); a.K = (int)d;
-                wh_launch_skinny(s, prec, false, a);
-            }
-            {
-                Prof pr(c, WH_KG_DEC_OTHER);
-                wh_launch_dec_self_attn(s, prec, c->dqkv, (char*)c->self_k + l * cache_l * esz,
-                                        (char*)c->self_v + l * cache_l * esz, c->datt, c->pos, (int)d, D.n_heads,
-                                        D.n_text_ctx, nb);
-            }
-            {
-                Prof pr(c, WH_KG_DEC_GEMM);
-                a = SkinnyArgs();
-                a.X = c->datt; a.ldx = d; a.W = L.o_w; a.bias = L.o_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
-                a.M = nb; a.N = (int)d; a.K = (int)d;
-                wh_launch_skinny(s, prec, true, a);
-            }
-            { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_layernorm(s, prec, c->dx, L.ln2_w, L.ln2_b, c->dxn, nb, (int)d); }
-            {
-                Prof pr(c, WH_KG_DEC_GEMM);
-                a = SkinnyArgs();
-                a.X = c->dxn; a.ldx = d; a.W = L.cq_w; a.bias = L.cq_b; a.C = c->dq; a.ldc = d;
-                a.M = nb; a.N = (int)d; a.K = (int)d;
-                wh_launch_skinny(s, prec, false, a);
-            }
-            {
-                Prof pr(c, WH_KG_DEC_CROSS_ATTN);
-                wh_launch_dec_cross_attn(s, prec, c->dq, (char*)c->cross_kv + (2 * l) * kv_stride * esz,
-                                         (char*)c->cross_kv + (2 * l + 1) * kv_stride * esz, c->cpart, c->cml, (int)S,
-                                         (int)d, D.n_heads, c->cross_splits, nb);
-            }
-            { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_cross_combine(s, prec, c->cpart, c->cml, c->datt, (int)d, D.n_heads, c->cross_splits, nb); }
-            {
-                Prof pr(c, WH_KG_DEC_GEMM);
-                a = SkinnyArgs();
-                a.X = c->datt; a.ldx = d; a.W = L.co_w; a.bias = L.co_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
-                a.M = nb; a.N = (int)d; a.K = (int)d;
-                wh_launch_skinny(s, prec, true, a);
-            }
-            { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_layernorm(s, prec, c->dx, L.ln3_w, L.ln3_b, c->dxn, nb, (int)d); }
-            {
-                Prof pr(c, WH_KG_DEC_GEMM);
-                a = SkinnyArgs();
-                a.X = c->dxn; a.ldx = d; a.W = L.fc1_w; a.bias = L.fc1_b; a.act = 1; a.C = c->dh; a.ldc = F;
-                a.M = nb; a.N = (int)F; a.K = (int)d;
-                wh_launch_skinny(s, prec, false, a);
-                a = SkinnyArgs();
-                a.X = c->dh; a.ldx = F; a.W = L.fc2_w; a.bias = L.fc2_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
-                a.M = nb; a.N = (int)d; a.K = (int)F;
-                wh_launch_skinny(s, prec, true, a);
-            }
-        }
-        if (step >= P - 1) {  // this position produces a token: final LN, tied LM head, masked argmax
-            { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_layernorm(s, prec, c->dx, m->dec_ln_w, m->dec_ln_b, c->dxn, nb, (int)d); }
-            {
-                Prof pr(c, WH_KG_DEC_GEMM);
+    // one decoder position = ~50 kernel launches; `emits` adds final LN + LM head + argmax
+    auto launch_step = [&](bool emits) {
+            for (int l = 0; l < D.dec_layers; l++) {
+                const DecLayerDev& L = m->dec[l];
                 SkinnyArgs a;
-                a.X = c->dxn; a.ldx = d; a.W = m->tok_emb; a.M = nb; a.N = D.vocab; a.K = (int)d;
-                a.pos_p = c->pos; a.n_prompt = P; a.mask_first = c->mask_first; a.mask_base = c->mask_base;
-                a.logits = d_logits; a.logits_rows = (int)logits_rows; a.part_val = c->part_val; a.part_idx = c->part_idx;
-                wh_launch_lm_head(s, prec, a);
+                {   // [embed +] LN1 + Q|K|V projection
+                    Prof pr(c, WH_KG_DEC_GEMM);
+                    a = SkinnyArgs();
+                    a.W = L.qkv_w; a.bias = L.qkv_b; a.C = c->dqkv; a.ldc = 3 * d;
+                    a.M = nb; a.N = (int)(3 * d); a.K = (int)d;
+                    a.xres = c->dx; a.ln_w = L.ln1_w; a.ln_b = L.ln1_b; a.pos_p = c->pos;
+                    if (l == 0) {
+                        a.xres_out = c->dx; a.tok_emb = m->tok_emb; a.pos_emb = m->dec_pos; a.feed = c->feed; a.feed_ld = ld;
+                    }
+                    wh_launch_dec_gemm(s, prec, false, l == 0 ? 2 : 1, a);
+                }
+                {
+                    Prof pr(c, WH_KG_DEC_OTHER);
+                    wh_launch_dec_self_attn(s, prec, c->dqkv, (char*)c->self_k + l * cache_l * esz,
+                                            (char*)c->self_v + l * cache_l * esz, c->datt, c->pos, (int)d, D.n_heads,
+                                            D.n_text_ctx, nb);
+                }
+                {   // self-attention out-proj + residual
+                    Prof pr(c, WH_KG_DEC_GEMM);
+                    a = SkinnyArgs();
+                    a.X = c->datt; a.ldx = d; a.W = L.o_w; a.bias = L.o_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
+                    a.M = nb; a.N = (int)d; a.K = (int)d;
+                    wh_launch_dec_gemm(s, prec, true, 0, a);
+                }
+                {   // LN2 + cross-attention query
+                    Prof pr(c, WH_KG_DEC_GEMM);
+                    a = SkinnyArgs();
+                    a.W = L.cq_w; a.bias = L.cq_b; a.C = c->dq; a.ldc = d; a.M = nb; a.N = (int)d; a.K = (int)d;
+                    a.xres = c->dx; a.ln_w = L.ln2_w; a.ln_b = L.ln2_b;
+                    wh_launch_dec_gemm(s, prec, false, 1, a);
+                }
+                {
+                    Prof pr(c, WH_KG_DEC_CROSS_ATTN);
+                    wh_launch_dec_cross_attn(s, prec, c->dq, (char*)c->cross_kv + (2 * l) * kv_stride * esz,
+                                             (char*)c->cross_kv + (2 * l + 1) * kv_stride * esz, c->cpart, c->cml, c->datt,
+                                             c->cross_tickets, (int)S, (int)d, D.n_heads, c->cross_splits, nb);
+                }
+                {   // cross-attention out-proj + residual
+                    Prof pr(c, WH_KG_DEC_GEMM);
+                    a = SkinnyArgs();
+                    a.X = c->datt; a.ldx = d; a.W = L.co_w; a.bias = L.co_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
+                    a.M = nb; a.N = (int)d; a.K = (int)d;
+                    wh_launch_dec_gemm(s, prec, true, 0, a);
+                }
+                {   // LN3 + fc1 + GELU, fc2 + residual
+                    Prof pr(c, WH_KG_DEC_GEMM);
+                    a = SkinnyArgs();
+                    a.W = L.fc1_w; a.bias = L.fc1_b; a.act = 1; a.C = c->dh; a.ldc = F; a.M = nb; a.N = (int)F; a.K = (int)d;
+                    a.xres = c->dx; a.ln_w = L.ln3_w; a.ln_b = L.ln3_b;
+                    wh_launch_dec_gemm(s, prec, false, 1, a);
+                }
+                {
+                    Prof pr(c, WH_KG_DEC_GEMM);
+                    a = SkinnyArgs();
+                    a.X = c->dh; a.ldx = F; a.W = L.fc2_w; a.bias = L.fc2_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
+                    a.M = nb; a.N = (int)d; a.K = (int)F;
+                    if (!emits && l == D.dec_layers - 1) { a.ticket = c->step_ticket; a.pos_w = c->pos; }  // prompt position: advance here
+                    wh_launch_dec_gemm(s, prec, true, 0, a);
+                }
             }
-            { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_argmax_finish(s, c->part_val, c->part_idx, n_tiles, c->pos, st, nb); }
+            if (emits) {  // final LN + tied LM head + masked argmax; the finish kernel advances the position
+                { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_layernorm(s, prec, c->dx, m->dec_ln_w, m->dec_ln_b, c->dxn, nb, (int)d); }
+                {
+                    Prof pr(c, WH_KG_DEC_GEMM);
+                    SkinnyArgs a;
+                    a.W = m->tok_emb; a.M = nb; a.N = D.vocab; a.K = (int)d;
+                    a.X = c->dxn; a.ldx = d;
+                    a.pos_p = c->pos; a.n_prompt = P; a.mask_first = c->mask_first; a.mask_base = c->mask_base;
+                    a.logits = d_logits; a.logits_rows = (int)logits_rows; a.part_val = c->part_val; a.part_idx = c->part_idx;
+                    wh_launch_lm_head(s, prec, a);
+                }
+                { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_argmax_finish(s, c->part_val, c->part_idx, n_tiles, c->pos, c->step_ticket, st, nb); }
+            }
+    };
+    // Positions 0 .. P-1 (the prompt, the last of which emits the first token) are launched eagerly;
+    // the remaining NEW-1 positions replay ONE captured hipGraph of an emitting step — every kernel
+    // reads the position from device memory, so the graph is position-independent.  The host then
+    // pays one graph launch per token instead of ~50 kernel launches (src/main.rs:793-826 is one ORT
+    // Run per token in the reference).
+    for (int step = 0; step < std::min(P, total_pos); step++) launch_step(step >= P - 1);
+    const int remaining = total_pos - P;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    const bool use_graph = remaining > 1 && !c->prof && !c->no_graph;
+    if (use_graph) {
+        CTX_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        launch_step(true);
+        CTX_HIP(c, hipStreamEndCapture(s, &graph));
+        CTX_HIP(c, hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+    }
+    for (int r = 0; r < remaining; r++) {
+        if (use_graph) {
+            hipError_t ge = hipGraphLaunch(gexec, s);
+            if (ge != hipSuccess) {
+                hipGraphExecDestroy(gexec);
+                hipGraphDestroy(graph);
+                return fail(c, WH_ERR_HIP, "hipGraphLaunch failed: %s", hipGetErrorString(ge));
+            }
+        } else {
+            launch_step(true);
         }
-        wh_launch_step_advance(s, c->pos);
-        // EOT early-out (src/main.rs:781-783, 820-822): poll the done flags every 8 generated tokens
-        const int gen = step - (P - 1);
-        if (gen >= 0 && (gen & 7) == 7 && step + 1 < total_pos) {
-            CTX_HIP(c, hipMemcpyAsync(done_h.data(), c->done, nb * 4, hipMemcpyDeviceToHost, s));
-            CTX_HIP(c, hipStreamSynchronize(s));
+        // EOT early-out (src/main.rs:781-783, 820-822): poll the done flags every 16 generated tokens
+        const int gen = r + 1;
+        if ((gen & 15) == 15 && r + 1 < remaining && p->n_forced == 0) {
+            hipError_t e1 = hipMemcpyAsync(done_h.data(), c->done, nb * 4, hipMemcpyDeviceToHost, s);
+            hipError_t e2 = hipStreamSynchronize(s);
+            if (e1 != hipSuccess || e2 != hipSuccess) {
+                if (use_graph) { hipGraphExecDestroy(gexec); hipGraphDestroy(graph); }
+                return fail(c, WH_ERR_HIP, "decode: polling the done flags failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+            }
             bool all = true;
             for (int b = 0; b < nb; b++) all = all && done_h[b];
             if (all) break;
         }
+    }
+    if (use_graph) {
+        hipGraphExecDestroy(gexec);
+        hipGraphDestroy(graph);
     }
     CTX_HIP(c, hipEventRecord(c->ev[3], s));
     // results
@@ -507,13 +550,14 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
     auto* c = new wh_ctx();
     c->m = m;
     c->max_batch = max_batch;
+    c->no_graph = getenv("WH_NO_GRAPH") != nullptr;
     const wh_dims& D = m->dims;
     const size_t B = max_batch, d = D.d_model, S = D.n_audio_ctx, F = D.ffn, C = D.n_mels, esz = m->esz;
     const size_t Ld = D.dec_layers, H = D.n_heads, TC = D.n_text_ctx;
     c->ldv = (int)align_up(S, 64);
     c->tok_ld = D.n_text_ctx + 1;
     // enough workgroups to cover the chip at small batch, no more than 16 key ranges
-    c->cross_splits = (int)std::min<size_t>(16, std::max<size_t>(1, 512 / B));
+    c->cross_splits = (int)std::min<size_t>(32, std::max<size_t>(1, 1024 / B));
     const size_t n_tiles = (D.vocab + 15) / 16;
     Carver cv;
     const size_t o_pcm = cv.take(B * WH_CLIP_SAMPLES * 4), o_raw = cv.take(B * C * RAW_LD * 4);
@@ -530,6 +574,7 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
     const size_t o_pv = cv.take(B * n_tiles * 4), o_pi = cv.take(B * n_tiles * 4);
     const size_t o_feed = cv.take(B * c->tok_ld * 4), o_out = cv.take(B * c->tok_ld * 4);
     const size_t o_nout = cv.take(B * 4), o_done = cv.take(B * 4), o_forced = cv.take(TC * 4), o_pos = cv.take(4);
+    const size_t o_ctk = cv.take(B * 4), o_stk = cv.take(4);
     const size_t o_m1 = cv.take((D.vocab / 32 + 1) * 4), o_m2 = cv.take((D.vocab / 32 + 1) * 4);
     const size_t o_ns = cv.take(B * 4), o_nf = cv.take(B * 4), o_si = cv.take(B * 4), o_fs = cv.take(B * 4), o_gm = cv.take(B * 4);
     c->ws_bytes = cv.off;
@@ -546,6 +591,7 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
     c->cpart = (float*)(w + o_cpart); c->cml = (float*)(w + o_cml); c->part_val = (float*)(w + o_pv); c->part_idx = (int*)(w + o_pi);
     c->feed = (int*)(w + o_feed); c->out_tokens = (int*)(w + o_out); c->n_out = (int*)(w + o_nout); c->done = (int*)(w + o_done);
     c->forced = (int*)(w + o_forced); c->pos = (int*)(w + o_pos);
+    c->cross_tickets = (int*)(w + o_ctk); c->step_ticket = (int*)(w + o_stk);
     c->mask_first = (unsigned*)(w + o_m1); c->mask_base = (unsigned*)(w + o_m2);
     c->d_nsamp = (int*)(w + o_ns); c->d_nframes = (int*)(w + o_nf); c->d_src_index = (int*)(w + o_si);
     c->d_frame_start = (int*)(w + o_fs); c->d_gmax = (unsigned*)(w + o_gm);
@@ -582,9 +628,10 @@ int wh_get_timings(const wh_ctx* c, wh_timing* out) {
     return WH_OK;
 }
 
-int wh_profile_enable(wh_ctx* c, int enable) {
+int wh_profile_enable(wh_ctx* c, int group_mask) {
     if (!c) return WH_ERR_ARG;
-    c->prof = enable != 0;
+    c->prof = group_mask != 0;
+    c->prof_mask = group_mask;
     return WH_OK;
 }
 int wh_profile_get(const wh_ctx* c, double* ms, int64_t* launches) {

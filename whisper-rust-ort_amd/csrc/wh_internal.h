@@ -52,6 +52,8 @@ struct wh_ctx {
     int enc_batch = 0;
     // profiling hooks
     bool prof = false;
+    int prof_mask = 0;  // bit g set: kernel group g is bracketed by events
+    bool no_graph = false;  // WH_NO_GRAPH=1: launch every decode step eagerly
     int prof_group = -1;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[WH_KG_COUNT];
     size_t prof_used[WH_KG_COUNT] = {0};
@@ -100,6 +102,7 @@ struct wh_ctx {
     float* part_val = nullptr;  // [B][n_tiles]
     int* part_idx = nullptr;
     int *feed = nullptr, *out_tokens = nullptr, *n_out = nullptr, *done = nullptr, *forced = nullptr, *pos = nullptr;
+    int *cross_tickets = nullptr, *step_ticket = nullptr;  // zeroed at creation, re-armed by their last arriver
     unsigned *mask_first = nullptr, *mask_base = nullptr;
     float* logits = nullptr;    // optional parity buffer (grown on demand)
     size_t logits_cap = 0;

@@ -33,7 +33,18 @@ struct SkinnyArgs {
     void* C = nullptr;
     long ldc = 0;
     int M = 0, N = 0, K = 0, act = 0;
-    // LM-head mode
+    // fused prologues: LayerNorm of xres (pro 1) or embedding + LayerNorm (pro 2)
+    const float* xres = nullptr;     // [M][K] f32 residual stream
+    float* xres_out = nullptr;       // pro 2: where the embedded rows are written
+    const float *ln_w = nullptr, *ln_b = nullptr;
+    const void* tok_emb = nullptr;   // [V][K] compute dtype
+    const float* pos_emb = nullptr;  // [n_text_ctx][K]
+    const int* feed = nullptr;
+    int feed_ld = 0;
+    // position advance by the last workgroup of the last kernel of a step
+    int* ticket = nullptr;
+    int* pos_w = nullptr;
+    // LM-head mode (pos_p is also read by the embedding prologue)
     const int* pos_p = nullptr;
     int n_prompt = 0;
     const unsigned* mask_first = nullptr;
@@ -73,17 +84,11 @@ void wh_launch_layernorm(hipStream_t s, int prec, const float* x, const float* w
 void wh_launch_enc_attn(hipStream_t s, int prec, const void* qk, const void* vT, void* out, int n_clips, int S, int d,
                         int n_heads, int ldv);
 
-void wh_launch_dec_embed(hipStream_t s, int prec, const void* tok_emb, const float* pos_emb, const int* feed,
-                         int feed_ld, const int* pos_p, float* x, int d, int B);
-void wh_launch_skinny(hipStream_t s, int prec, bool out_f32, const SkinnyArgs& a);
+void wh_launch_dec_gemm(hipStream_t s, int prec, bool out_f32, int pro, const SkinnyArgs& a);
 void wh_launch_lm_head(hipStream_t s, int prec, const SkinnyArgs& a);
-void wh_launch_argmax_finish(hipStream_t s, const float* part_val, const int* part_idx, int n_tiles, const int* pos_p,
-                             const DecodeState& st, int B);
-void wh_launch_step_advance(hipStream_t s, int* pos_p);
+void wh_launch_argmax_finish(hipStream_t s, const float* part_val, const int* part_idx, int n_tiles, int* pos_p,
+                             int* ticket, const DecodeState& st, int B);
 void wh_launch_dec_self_attn(hipStream_t s, int prec, const void* qkv, void* kc, void* vc, void* out, const int* pos_p,
                              int d, int n_heads, int tc, int B);
-size_t wh_cross_attn_smem(int S, int d, int n_heads, int splits);
 void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void* ck, const void* cv, float* part,
-                              float* ml, int S, int d, int n_heads, int splits, int B);
-void wh_launch_cross_combine(hipStream_t s, int prec, const float* part, const float* ml, void* out, int d, int n_heads,
-                             int splits, int B);
+                              float* ml, void* out, int* tickets, int S, int d, int n_heads, int splits, int B);
