@@ -213,20 +213,14 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        from whisper_rust_ort_amd import sharding
+        dev_t = "cuda" if backend == "nccl" else "cpu"
+        elapsed = sharding.max_over_ranks(dist, elapsed, dev_t)
         # the path's only exchange: fixed-stride result records gathered to every rank
-        rec = torch.zeros((a.clips, 2 + len(prompt) + a.max_new_tokens), dtype=torch.int32)
-        for i, tk in enumerate(toks):
-            rec[i, 0] = rank * a.clips + i
-            rec[i, 1] = len(tk)
-            rec[i, 2:2 + len(tk)] = torch.from_numpy(tk.astype(np.int32))
-        rec = rec.cuda() if backend == "nccl" else rec
-        out = [torch.zeros_like(rec) for _ in range(world)]
-        dist.all_gather(out, rec)
-        n_results = sum(int((o[:, 1] > 0).sum()) for o in out)
+        rec = sharding.pack_records(sharding.shard_clip_ids(rank, world, a.clips), toks, len(prompt) + a.max_new_tokens)
+        allrec = sharding.gather_records(dist, rec, dev_t)
+        n_results = len(sharding.unpack_records(allrec))
+        assert n_results == world * a.clips
     else:
         n_results = len(toks)
 

@@ -1,0 +1,111 @@
+"""The C++ CLI (reference flag surface + emitters) end to end on the GPU."""
+import json
+import os
+import subprocess
+import wave
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from whisper_rust_ort_amd import binding as wb
+from whisper_rust_ort_amd import modelspec as ms
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "whisper-rust-ort_amd", "whisper_bench")
+
+
+def _write_wav(path, pcm):
+    x = np.clip(np.round(pcm * 32767.0), -32768, 32767).astype(np.int16)
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(x.tobytes())
+    return x.astype(np.float32) / np.float32(32768)
+
+
+def test_cli_end_to_end_matches_oracle_tokens(tmp_path):
+    if wb.device_count() < 1:
+        pytest.fail("no MI355X visible")
+    adir = tmp_path / "audio"
+    adir.mkdir()
+    mdir = tmp_path / "model"
+    mdir.mkdir()
+    dims = ms.PRESETS["nano"]
+    # a real model directory: config.json + model.safetensors (HF layout) + generation_config.json
+    sd = ms.synth_state_dict(dims, 7)
+    hdr, blobs, off = {}, [], 0
+    for name, arr in sd.items():
+        b = arr.astype("<f4").tobytes()
+        hdr[name] = {"dtype": "F32", "shape": list(arr.shape), "data_offsets": [off, off + len(b)]}
+        blobs.append(b)
+        off += len(b)
+    hj = json.dumps(hdr).encode()
+    (mdir / "model.safetensors").write_bytes(len(hj).to_bytes(8, "little") + hj + b"".join(blobs))
+    (mdir / "config.json").write_text(json.dumps({
+        "num_mel_bins": 80, "d_model": dims.d_model, "encoder_attention_heads": dims.n_heads, "decoder_attention_heads": dims.n_heads,
+        "encoder_layers": dims.enc_layers, "decoder_layers": dims.dec_layers, "encoder_ffn_dim": dims.ffn, "decoder_ffn_dim": dims.ffn,
+        "vocab_size": dims.vocab, "max_source_positions": 1500, "max_target_positions": 448}))
+    (mdir / "generation_config.json").write_text(json.dumps({"suppress_tokens": [432, 182], "begin_suppress_tokens": [1]}))
+    # tokenizer.json so prompt ids resolve inside the nano vocabulary
+    (mdir / "tokenizer.json").write_text(json.dumps({"model": {"vocab": {}}, "added_tokens": [
+        {"id": 2, "content": "<|endoftext|>", "special": True}, {"id": 3, "content": "<|startoftranscript|>", "special": True},
+        {"id": 5, "content": "<|en|>", "special": True}, {"id": 7, "content": "<|transcribe|>", "special": True},
+        {"id": 9, "content": "<|notimestamps|>", "special": True}]}))
+    clips = {"b_short.wav": ms.synth_clip(71)[:100000], "a_long.wav": np.concatenate([ms.synth_clip(72), ms.synth_clip(73)[:250000]])}
+    pcm = {k: _write_wav(str(adir / k), v) for k, v in clips.items()}
+    out = tmp_path / "res"
+    r = subprocess.run([CLI, "--audio-dir", str(adir), "--onnx-dir", str(mdir), "--max-new-tokens", "6", "--precision", "f32",
+                        "--out-csv", str(out / "p.csv"), "--out-json", str(out / "p.json"), "--out-summary-json", str(out / "s.json"),
+                        "--write-txt", "--warmup", "1", "--intra-op", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[0] == "DONE" and lines[1] == "Config used:" and lines[2] == "{"
+    assert any(l.startswith("End-to-end p95(s): ") for l in lines)
+    rows = json.loads((out / "p.json").read_text())
+    assert [x["file"] for x in rows] == ["a_long.wav", "b_short.wav"]            # sorted (src/main.rs:1122)
+    w = ms.flatten_state_dict(dims, sd)
+    for row in rows:
+        x = pcm[row["file"]]
+        assert row["duration_s"] == round(len(x) / 16000.0, 3)
+        mel_full = orc.log_mel(x, 80)
+        texts = []
+        for off in wb.longform_plan(len(x)):
+            enc = orc.encoder(dims, w, orc.window_mel(mel_full, off // 160, 3000))
+            toks, _ = orc.decode_greedy(dims, w, enc, [3, 5, 7, 9], 6, 2, [432, 182], [1])
+            gen = toks[4:].tolist()
+            if gen and gen[-1] == 2:
+                gen.pop()
+            texts.append("")  # every id is outside the (empty) vocab → decodes to "" → "[EMPTY]" is dropped (:936-942)
+        assert row["text"] == ""
+    s = json.loads((out / "s.json").read_text())
+    txt = (out / "s.json").read_text()
+    assert list(s.keys()) == sorted(s.keys())                                    # serde_json map order
+    assert s["n_files"] == 2 and s["config_used"]["intra_op"] == 1 and s["max_new_tokens"] == 6
+    assert list(s["breakdown_s"].keys()) == ["decode_s", "load_s", "model_only_s", "preprocess_s"]
+    assert list(s["latency_end_to_end_s"].keys()) == ["max", "mean", "median", "min", "p90", "p95"]
+    assert txt.startswith('{\n  "breakdown_s": {\n    "decode_s": {\n      "max": ')
+    csv = (out / "p.csv").read_text().splitlines()
+    assert csv[0] == "file,duration_s,end_to_end_s,rtf,text" and csv[1].startswith("a_long.wav,45.625,")
+    assert (out / "a_long.transcript.txt").read_text() == "\n"
+
+
+def test_cli_token_fallback_text_matches_library(tmp_path):
+    """Without a tokenizer the reference prints "[TOKENS:…]" (src/main.rs:644-647): the CLI's text must be
+    exactly the ids the library returns for the same synthetic model and audio."""
+    adir = tmp_path / "audio"
+    adir.mkdir()
+    x = _write_wav(str(adir / "c.wav"), ms.synth_clip(80))
+    out = tmp_path / "res"
+    r = subprocess.run([CLI, "--audio-dir", str(adir), "--onnx-dir", "synthetic:base:1234", "--max-new-tokens", "10",
+                        "--out-csv", str(out / "p.csv"), "--out-json", str(out / "p.json"), "--out-summary-json", str(out / "s.json")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    row = json.loads((out / "p.json").read_text())[0]
+    m = wb.Model("synthetic:base:1234", 0, wb.WH_PREC_BF16)
+    c = wb.Context(m, 1)
+    toks = c.transcribe_batch([x], wb.DecodeParams([50258, 50259, 50359, 50363], 10, 50257))[0]
+    gen = toks[4:].tolist()
+    if gen and gen[-1] == 50257:
+        gen.pop()
+    assert row["text"] == "[TOKENS:" + " ".join(str(t) for t in gen) + "]"
+    assert row["rtf"] > 0 and row["end_to_end_s"] > 0

@@ -1,0 +1,217 @@
+"""Host side above the C ABI (whisper-rust-ort_amd/host): statistics, emitters, resampler, WAV,
+stitcher, detokeniser — held to the reference's semantics (src/main.rs) and to the byte format of its
+archived outputs (results.old/.../inference_summary.json: alphabetical keys, ryu float text)."""
+import ctypes as C
+import json
+import math
+import os
+import struct
+import subprocess
+import wave
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "whisper-rust-ort_amd")
+
+
+@pytest.fixture(scope="module")
+def H():
+    so = os.path.join(PKG, "libwh_host.so")
+    assert os.path.exists(so), "run __graft_entry__.build()"
+    L = C.CDLL(so)
+    L.whh_fmt_f64.argtypes = [C.c_double, C.c_char_p, C.c_size_t]
+    L.whh_fmt_f64.restype = C.c_size_t
+    L.whh_percentile.argtypes = [C.POINTER(C.c_double), C.c_size_t, C.c_double]
+    L.whh_percentile.restype = C.c_double
+    L.whh_stat_block.argtypes = [C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_double)]
+    L.whh_stat_json.argtypes = [C.POINTER(C.c_double), C.c_size_t, C.c_char_p, C.c_size_t]
+    L.whh_stat_json.restype = C.c_size_t
+    for f in (L.whh_csv, L.whh_per_file_json):
+        f.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t, C.c_char_p, C.c_size_t]
+        f.restype = C.c_size_t
+    L.whh_resample_linear.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_uint, C.c_uint, C.POINTER(C.c_float), C.c_size_t]
+    L.whh_resample_linear.restype = C.c_size_t
+    L.whh_stitch.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    L.whh_stitch.restype = C.c_size_t
+    L.whh_word_overlap.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    L.whh_word_overlap.restype = C.c_size_t
+    L.whh_decode_tokens.argtypes = [C.POINTER(C.c_longlong), C.c_size_t, C.c_char_p, C.c_char_p, C.c_size_t]
+    L.whh_decode_tokens.restype = C.c_size_t
+    L.whh_special_tokens.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_longlong)]
+    L.whh_load_wav.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_double)]
+    return L
+
+
+def _s(fn, *a):
+    buf = C.create_string_buffer(1 << 16)
+    fn(*a, buf, len(buf))
+    return buf.value.decode()
+
+
+def _d(xs):
+    return (C.c_double * len(xs))(*xs)
+
+
+def test_f64_text_matches_serde_json_ryu(H):
+    cases = {14.884440201999999: "14.884440201999999", 0.000482736: "0.000482736", 301.574: "301.574", 1.0: "1.0",
+             0.049356: "0.049356", 100.0: "100.0", 1e-5: "0.00001", 1e-6: "1e-6", 1.5e-7: "1.5e-7", 1e16: "1e16",
+             1234567890123456.0: "1234567890123456.0", 12345678901234567.0: "1.2345678901234568e16", 0.1 + 0.2: "0.30000000000000004",
+             -2.5: "-2.5", 0.0: "0.0"}
+    for v, want in cases.items():
+        assert _s(H.whh_fmt_f64, v) == want, (v, want)
+        if v:
+            assert float(_s(H.whh_fmt_f64, v)) == v
+    assert _s(H.whh_fmt_f64, float("nan")) == "null" and _s(H.whh_fmt_f64, float("inf")) == "null"
+    rng = np.random.Generator(np.random.PCG64(1))
+    for v in np.concatenate([rng.uniform(0, 1, 200), rng.uniform(0, 1e6, 200), 10.0 ** rng.uniform(-12, 20, 200)]):
+        txt = _s(H.whh_fmt_f64, float(v))
+        assert float(txt) == float(v) and len(txt) <= len(repr(float(v))) + 2
+
+
+def test_percentile_and_stat_block_follow_the_reference(H):
+    def ref_percentile(xs, p):  # src/main.rs:1021-1031
+        if not xs:
+            return math.nan
+        xs = sorted(xs)
+        k = (len(xs) - 1) * (p / 100.0)
+        f, c = math.floor(k), math.ceil(k)
+        return xs[f] if f == c else xs[f] + (xs[c] - xs[f]) * (k - f)
+    rng = np.random.Generator(np.random.PCG64(2))
+    for n in (1, 2, 3, 4, 10, 11, 64, 512):
+        xs = rng.uniform(0, 10, n).tolist()
+        for p in (0, 50, 90, 95, 100):
+            assert H.whh_percentile(_d(xs), n, p) == ref_percentile(xs, p)
+        out = (C.c_double * 6)()
+        H.whh_stat_block(_d(xs), n, out)
+        s = sorted(xs)
+        assert out[0] == s[0] and out[4] == s[-1] and out[1] == s[n // 2]      # UPPER median (:1039)
+        assert out[2] == ref_percentile(xs, 90) and out[3] == ref_percentile(xs, 95)
+        assert out[5] == sum(s) / n
+    out = (C.c_double * 6)()
+    H.whh_stat_block(_d([]), 0, out)
+    assert all(math.isnan(v) for v in out)
+    assert _s(H.whh_stat_json, _d([]), 0) == '{\n  "max": null,\n  "mean": null,\n  "median": null,\n  "min": null,\n  "p90": null,\n  "p95": null\n}'
+    # n = 1 sample block exactly as archived by the reference (alphabetical keys, 2-space indent)
+    assert _s(H.whh_stat_json, _d([14.031795815]), 1) == ('{\n  "max": 14.031795815,\n  "mean": 14.031795815,\n  "median": 14.031795815,\n'
+                                                          '  "min": 14.031795815,\n  "p90": 14.031795815,\n  "p95": 14.031795815\n}')
+
+
+def test_rows_csv_and_per_file_json(H):
+    files = b"audio.wav\0b,c.wav\0"
+    texts = 'Meet Emma, a "designer".\0plain\0'.encode()
+    dur, e2e = _d([301.5744375, 30.0]), _d([14.884440201999999, 0.00449])
+    csv = _s(H.whh_csv, files, texts, dur, e2e, 2)
+    assert csv == ('file,duration_s,end_to_end_s,rtf,text\n'
+                   'audio.wav,301.574,14.8844,0.049356,"Meet Emma, a ""designer""."\n'
+                   '"b,c.wav",30.000,0.0045,0.000150,plain\n')
+    js = _s(H.whh_per_file_json, files, texts, dur, e2e, 2)
+    assert js.startswith('[\n  {\n    "file": "audio.wav",\n    "duration_s": 301.574,\n    "end_to_end_s": 14.8844,\n    "rtf": 0.049356,\n    "text": "Meet Emma, a \\"designer\\"."\n  },\n  {')
+    rows = json.loads(js)
+    assert list(rows[0].keys()) == ["file", "duration_s", "end_to_end_s", "rtf", "text"]     # struct order (:1054-1060)
+    assert rows[1] == {"file": "b,c.wav", "duration_s": 30.0, "end_to_end_s": 0.0045, "rtf": 0.00015, "text": "plain"}
+    assert _s(H.whh_per_file_json, b"", b"", _d([]), _d([]), 0) == "[]"
+
+
+def test_resample_linear_matches_reference_formula(H):
+    def ref(x, sr_in, sr_out):  # src/main.rs:207-226
+        if sr_in == sr_out:
+            return x.copy()
+        ratio = sr_out / sr_in
+        n_out = int(round(len(x) * ratio))
+        y = np.zeros(n_out, np.float32)
+        for i in range(n_out):
+            t = i / ratio
+            i0 = math.floor(t)
+            a = t - i0
+            s0 = x[i0] if 0 <= i0 < len(x) else np.float32(0)
+            s1 = x[i0 + 1] if 0 <= i0 + 1 < len(x) else np.float32(0)
+            y[i] = np.float32(1.0 - a) * s0 + np.float32(a) * s1
+        return y
+    rng = np.random.Generator(np.random.PCG64(3))
+    x = rng.uniform(-1, 1, 4410).astype(np.float32)
+    for sr in (44100, 8000, 22050, 48000, 16000):
+        want = ref(x, sr, 16000)
+        out = np.zeros(len(want) + 8, np.float32)
+        n = H.whh_resample_linear(x.ctypes.data_as(C.POINTER(C.c_float)), x.size, sr, 16000, out.ctypes.data_as(C.POINTER(C.c_float)), out.size)
+        assert n == len(want)
+        np.testing.assert_array_equal(out[:n], want)
+
+
+def test_wav_reader_formats(H, tmp_path):
+    rng = np.random.Generator(np.random.PCG64(4))
+    x = rng.integers(-20000, 20000, size=(1600, 2)).astype(np.int16)
+    p = str(tmp_path / "s16.wav")
+    with wave.open(p, "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(16000); w.writeframes(x.tobytes())
+    out = np.zeros(2000, np.float32); n = C.c_size_t(); dur = C.c_double()
+    assert H.whh_load_wav(p.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), out.size, C.byref(n), C.byref(dur)) == 0
+    want = ((x[:, 0].astype(np.float32) / np.float32(32768)) + (x[:, 1].astype(np.float32) / np.float32(32768))) / np.float32(2)
+    assert n.value == 1600 and abs(dur.value - 0.1) < 1e-12
+    np.testing.assert_array_equal(out[:1600], want)                                   # channel mean (:294-301)
+    u8 = rng.integers(0, 256, size=800).astype(np.uint8)
+    p8 = str(tmp_path / "u8.wav")
+    with wave.open(p8, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(1); w.setframerate(8000); w.writeframes(u8.tobytes())
+    assert H.whh_load_wav(p8.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), out.size, C.byref(n), C.byref(dur)) == 0
+    assert n.value == 1600                                                             # 8 kHz → 16 kHz
+    assert out[0] == (np.float32(u8[0]) - np.float32(128)) / np.float32(128)           # (:276-283)
+    pf = str(tmp_path / "f32.wav")
+    f = rng.uniform(-1, 1, 320).astype(np.float32)
+    with open(pf, "wb") as fh:
+        fh.write(b"RIFF" + struct.pack("<I", 36 + f.nbytes) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 3, 1, 16000, 64000, 4, 32)
+                 + b"data" + struct.pack("<I", f.nbytes) + f.tobytes())
+    assert H.whh_load_wav(pf.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), out.size, C.byref(n), C.byref(dur)) == 0
+    np.testing.assert_array_equal(out[:320], f)
+    p24 = str(tmp_path / "s24.wav")
+    with wave.open(p24, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(3); w.setframerate(16000); w.writeframes(b"\0" * 30)
+    assert H.whh_load_wav(p24.encode(), None, 0, C.byref(n), C.byref(dur)) == 1        # "Unsupported decoded sample format" (:303)
+    assert H.whh_load_wav(b"/nonexistent.wav", None, 0, C.byref(n), C.byref(dur)) == 1
+
+
+def test_stitcher(H):
+    assert H.whh_word_overlap(b"the quick brown fox", b"Brown FOX jumps", 16) == 2   # case-insensitive (:686-696)
+    assert H.whh_word_overlap(b"a b c", b"x y", 16) == 0
+    assert H.whh_word_overlap(b"a b c d", b"c d e", 1) == 0                            # only suffixes of length <= max_words
+    chunks = b"  Hello there general \0general Kenobi you are\0\0 you are a bold one \0unrelated tail\0"
+    assert _s(H.whh_stitch, chunks, 5) == "Hello there general Kenobi you are a bold one unrelated tail"
+    assert _s(H.whh_stitch, b"only\0", 1) == "only" and _s(H.whh_stitch, b"\0 \0", 2) == ""
+
+
+def test_prompt_ids_and_token_fallback(H, tmp_path):
+    out = (C.c_longlong * 5)()
+    assert H.whh_special_tokens(b"en", b"transcribe", b"", out) == 0
+    assert list(out) == [50258, 50257, 50259, 50359, 50363]                            # src/main.rs:549-566
+    H.whh_special_tokens(b"hi", b"translate", b"", out)
+    assert list(out) == [50258, 50257, 50276, 50358, 50363]
+    H.whh_special_tokens(b"xx", b"yy", b"", out)
+    assert list(out)[2:4] == [50259, 50359]                                            # defaults
+    toks = (C.c_longlong * 3)(11, 22, 33)
+    assert _s(H.whh_decode_tokens, toks, 3, b"") == "[TOKENS:11 22 33]"               # :644-647
+    many = (C.c_longlong * 250)(*range(250))
+    assert _s(H.whh_decode_tokens, many, 250, b"").count(" ") == 199                   # first 200 ids only
+    # byte-level BPE decode with a local tokenizer.json (skip_special_tokens = true)
+    tj = {"model": {"vocab": {"Hello": 0, "Ġworld": 1, "!": 2, "Ã©": 3}},
+          "added_tokens": [{"id": 4, "content": "<|endoftext|>", "special": True}, {"id": 5, "content": "<|startoftranscript|>", "special": True},
+                           {"id": 6, "content": "<|en|>", "special": True}, {"id": 7, "content": "<|transcribe|>", "special": True},
+                           {"id": 8, "content": "<|notimestamps|>", "special": True}]}
+    p = tmp_path / "tokenizer.json"
+    p.write_text(json.dumps(tj))
+    ids = (C.c_longlong * 6)(5, 0, 1, 3, 2, 4)
+    assert _s(H.whh_decode_tokens, ids, 6, str(p).encode()) == "Hello worldé!"
+    assert H.whh_special_tokens(b"en", b"transcribe", str(p).encode(), out) == 0 and list(out) == [5, 4, 6, 7, 8]
+    assert H.whh_special_tokens(b"de", b"transcribe", str(p).encode(), out) == 1       # "Tokenizer missing token" (:533)
+
+
+def test_cli_flag_surface_and_loud_failure_without_gpu():
+    cli = os.path.join(PKG, "whisper_bench")
+    assert os.path.exists(cli)
+    h = subprocess.run([cli, "--help"], capture_output=True, text=True).stdout
+    for flag in ("--audio-dir", "--model-id", "--onnx-dir", "--language", "--task", "--max-new-tokens", "--warmup", "--limit-files",
+                 "--discovery-best-json", "--out-csv", "--out-json", "--out-summary-json", "--intra-op", "--inter-op", "--write-txt",
+                 "--tokenizer-json", "--timestamps", "--chunk-parallelism", "--chunk-length-s", "--overlap-s"):
+        assert flag in h, flag                                                          # src/main.rs:23-86
+    r = subprocess.run([cli, "--bogus", "1"], capture_output=True, text=True)
+    assert r.returncode == 2 and "unexpected argument" in r.stderr

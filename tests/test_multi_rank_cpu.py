@@ -1,0 +1,82 @@
+"""N > 1 path on CPU: two ranks over gloo shard the clip set, 'transcribe' their shard (here with the
+CPU oracle on the nano model — the checker standing in for the GPU call), gather the fixed-stride
+records and must reproduce the single-process result in clip order."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from whisper_rust_ort_amd import modelspec as ms  # noqa: E402
+from whisper_rust_ort_amd import sharding  # noqa: E402
+
+CLIPS_PER_RANK, MAX_NEW, PROMPT, EOT = 2, 6, [3, 5, 7, 9], 2
+
+
+def _transcribe(clip_id):
+    from oracle import oracle as orc
+    dims = ms.PRESETS["nano"]
+    w = ms.flatten_state_dict(dims, ms.synth_state_dict(dims, 7))
+    pcm = ms.synth_clip(clip_id)[:48000]                      # 3 s, zero-padded window like :899-905
+    mel = orc.window_mel(orc.log_mel(pcm, 80), 0, 3000)
+    toks, _ = orc.decode_greedy(dims, w, orc.encoder(dims, w, mel), PROMPT, MAX_NEW, EOT)
+    return toks
+
+
+def _worker(rank, world, port, q):
+    os.environ["OMP_NUM_THREADS"] = "2"
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ids = sharding.shard_clip_ids(rank, world, CLIPS_PER_RANK)
+    toks = [_transcribe(i) for i in ids]
+    dist.barrier()
+    elapsed = sharding.max_over_ranks(dist, 1.0 + rank)        # MAX over ranks
+    rec = sharding.pack_records(ids, toks, len(PROMPT) + MAX_NEW)
+    allrec = sharding.gather_records(dist, rec)
+    q.put((rank, elapsed, allrec))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_gather_matches_single_process():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = [_transcribe(i) for i in range(world * CLIPS_PER_RANK)]
+    for rank, elapsed, allrec in got:
+        assert elapsed == 2.0                                   # max(1.0, 2.0)
+        rows = sharding.unpack_records(allrec)
+        assert [cid for cid, _ in rows] == list(range(world * CLIPS_PER_RANK))
+        for (cid, tk), r in zip(rows, ref):
+            assert tk.tolist() == r.tolist()
+
+
+def test_record_packing_roundtrip_and_bounds():
+    toks = [np.array([1, 2, 3]), np.array([], np.int64), np.arange(10)]
+    rec = sharding.pack_records([7, 3, 5], toks, 10)
+    assert rec.shape == (3, 12) and rec.dtype == np.int32
+    rows = sharding.unpack_records(rec)
+    assert [c for c, _ in rows] == [3, 5, 7]
+    assert rows[2][1].tolist() == [1, 2, 3] and rows[0][1].tolist() == []
+    with pytest.raises(ValueError):
+        sharding.pack_records([0], [np.arange(11)], 10)
+    assert sharding.shard_clip_ids(3, 8, 64) == list(range(192, 256))

@@ -45,7 +45,33 @@ def build(verbose: bool = False, force: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    build_host(verbose, force)
     return OUT
+
+
+HOST = os.path.join(HERE, "host")
+HOST_SO = os.path.join(HERE, "libwh_host.so")
+CLI = os.path.join(HERE, "whisper_bench")
+
+
+def build_host(verbose: bool = False, force: bool = False) -> None:
+    """The host side above the C ABI (C++, because the reference's host is compiled Rust and Rust is
+    not in this image): the CLI `whisper_bench` and `libwh_host.so` (host helpers for the tests)."""
+    gxx = os.environ.get("CXX", "g++")
+    hdr = [os.path.join(HOST, "wh_host.h"), os.path.join(CSRC, "wh_json.h"), os.path.join(HERE, "..", "include", "whisper_hip.h")]
+    src = os.path.join(HOST, "wh_host_capi.cpp")
+    if force or _stale(HOST_SO, [src] + hdr):
+        cmd = [gxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", HOST_SO, src]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    src = os.path.join(HOST, "whisper_bench.cpp")
+    if force or _stale(CLI, [src, OUT] + hdr):
+        cmd = [gxx, "-O2", "-std=c++17", "-Wall", "-pthread", "-o", CLI, src, "-L" + HERE, "-lwhisper_hip",
+               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
 
 
 if __name__ == "__main__":

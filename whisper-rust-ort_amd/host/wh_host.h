@@ -1,0 +1,438 @@
+// wh_host.h — host-side pieces of the reference's binary that sit either side of the hot path,
+// restated in C++ (Rust is not available in this image): statistics + emitters byte-compatible with
+// serde_json / the csv crate, WAV reader + linear resampler, prompt ids, token → text fallback and
+// byte-level BPE decode, long-form stitcher.  Citations: /root/reference/src/main.rs.
+#pragma once
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../csrc/wh_json.h"
+
+namespace whhost {
+
+// ---------------------------------------------------------------------------------------------
+// f64 → text exactly as serde_json (ryu `format_finite`): shortest round-trip digits, decimal
+// notation while -5 < kk <= 16 else d.ddde±x; integers keep a trailing ".0"; NaN/inf → null.
+// ---------------------------------------------------------------------------------------------
+inline std::string fmt_f64(double v) {
+    if (!std::isfinite(v)) return "null";
+    if (v == 0.0) return std::signbit(v) ? "-0.0" : "0.0";
+    char buf[64];
+    int prec = 1;
+    for (; prec <= 17; prec++) {
+        snprintf(buf, sizeof buf, "%.*e", prec - 1, v);
+        if (strtod(buf, nullptr) == v) break;
+    }
+    // buf = [-]d[.ddd]e±XX
+    std::string s(buf);
+    bool neg = s[0] == '-';
+    if (neg) s.erase(0, 1);
+    size_t epos = s.find('e');
+    int exp10 = atoi(s.c_str() + epos + 1);
+    std::string digits = s.substr(0, epos);
+    digits.erase(std::remove(digits.begin(), digits.end(), '.'), digits.end());
+    while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+    const int len = (int)digits.size();
+    const int kk = exp10 + 1;  // 10^(kk-1) <= v < 10^kk
+    const int k = kk - len;
+    std::string out;
+    if (0 <= k && kk <= 16) {  // 1234e7 -> 12340000000.0
+        out = digits + std::string((size_t)k, '0') + ".0";
+    } else if (0 < kk && kk <= 16) {  // 1234e-2 -> 12.34
+        out = digits.substr(0, (size_t)kk) + "." + digits.substr((size_t)kk);
+    } else if (-5 < kk && kk <= 0) {  // 1234e-6 -> 0.001234
+        out = "0." + std::string((size_t)(-kk), '0') + digits;
+    } else if (len == 1) {  // 1e30
+        out = digits + "e" + std::to_string(kk - 1);
+    } else {  // 1234e30 -> 1.234e33
+        out = digits.substr(0, 1) + "." + digits.substr(1) + "e" + std::to_string(kk - 1);
+    }
+    return neg ? "-" + out : out;
+}
+
+inline std::string json_escape(const std::string& s) {  // serde_json string escaping
+    std::string o = "\"";
+    for (unsigned char c : s) {
+        switch (c) {
+            case '"': o += "\\\""; break;
+            case '\\': o += "\\\\"; break;
+            case '\n': o += "\\n"; break;
+            case '\r': o += "\\r"; break;
+            case '\t': o += "\\t"; break;
+            case '\b': o += "\\b"; break;
+            case '\f': o += "\\f"; break;
+            default:
+                if (c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); o += b; }
+                else o += (char)c;
+        }
+    }
+    return o + "\"";
+}
+
+// ---------------------------------------------------------------------------------------------
+// statistics — src/main.rs:1021-1048
+// ---------------------------------------------------------------------------------------------
+inline double percentile(std::vector<double> xs, double p) {  // :1021-1031
+    if (xs.empty()) return NAN;
+    std::sort(xs.begin(), xs.end());
+    double k = ((double)xs.size() - 1.0) * (p / 100.0);
+    size_t f = (size_t)std::floor(k), c = (size_t)std::ceil(k);
+    if (f == c) return xs[f];
+    return xs[f] + (xs[c] - xs[f]) * (k - (double)f);
+}
+
+struct StatBlock { double min, median, p90, p95, max, mean; };
+
+inline StatBlock stat_block(const std::vector<double>& xs) {  // :1033-1048 (median = v[len/2])
+    std::vector<double> v = xs;
+    std::sort(v.begin(), v.end());
+    StatBlock s;
+    s.min = v.empty() ? NAN : v.front();
+    s.max = v.empty() ? NAN : v.back();
+    double sum = 0;
+    for (double x : v) sum += x;
+    s.mean = v.empty() ? NAN : sum / (double)v.size();
+    s.median = v.empty() ? NAN : v[v.size() / 2];
+    s.p90 = percentile(xs, 90.0);
+    s.p95 = percentile(xs, 95.0);
+    return s;
+}
+
+// A tiny ordered-or-sorted JSON writer: serde_json::json! maps serialise with keys in ALPHABETICAL
+// order (no preserve_order feature), derived structs in declaration order.
+struct JVal {
+    enum Kind { Raw, Obj } kind = Raw;
+    std::string raw;                                   // already-encoded scalar
+    std::vector<std::pair<std::string, JVal>> fields;  // object
+    bool sorted = true;
+    static JVal num(double v) { JVal j; j.raw = fmt_f64(v); return j; }
+    static JVal integer(long long v) { JVal j; j.raw = std::to_string(v); return j; }
+    static JVal boolean(bool b) { JVal j; j.raw = b ? "true" : "false"; return j; }
+    static JVal str(const std::string& s) { JVal j; j.raw = json_escape(s); return j; }
+    static JVal obj(bool sorted_keys = true) { JVal j; j.kind = Obj; j.sorted = sorted_keys; return j; }
+    JVal& set(const std::string& k, JVal v) { fields.emplace_back(k, std::move(v)); return *this; }
+    void write(std::string& out, int indent) const {  // serde_json PrettyFormatter, 2 spaces
+        if (kind == Raw) { out += raw; return; }
+        if (fields.empty()) { out += "{}"; return; }
+        std::vector<const std::pair<std::string, JVal>*> order;
+        for (auto& f : fields) order.push_back(&f);
+        if (sorted) std::stable_sort(order.begin(), order.end(), [](auto a, auto b) { return a->first < b->first; });
+        out += "{\n";
+        for (size_t i = 0; i < order.size(); i++) {
+            out += std::string((size_t)(indent + 2), ' ') + json_escape(order[i]->first) + ": ";
+            order[i]->second.write(out, indent + 2);
+            out += (i + 1 < order.size()) ? ",\n" : "\n";
+        }
+        out += std::string((size_t)indent, ' ') + "}";
+    }
+    std::string pretty() const { std::string o; write(o, 0); return o; }
+};
+
+inline JVal stat_json(const StatBlock& s) {
+    return JVal::obj().set("min", JVal::num(s.min)).set("median", JVal::num(s.median)).set("p90", JVal::num(s.p90))
+        .set("p95", JVal::num(s.p95)).set("max", JVal::num(s.max)).set("mean", JVal::num(s.mean));
+}
+
+// ---------------------------------------------------------------------------------------------
+// rows + emitters — src/main.rs:1053-1060, 1193-1199, 1215-1232
+// ---------------------------------------------------------------------------------------------
+struct RowOut { std::string file; double duration_s, end_to_end_s, rtf; std::string text; };
+
+inline double round_to(double v, double scale) { return std::round(v * scale) / scale; }  // f64::round: half away from zero
+
+inline RowOut make_row(const std::string& file, double dur, double e2e, const std::string& text) {  // :1190-1199
+    RowOut r;
+    r.file = file;
+    double rtf = e2e / std::max(dur, 1e-9);
+    r.duration_s = round_to(dur, 1000.0);
+    r.end_to_end_s = round_to(e2e, 10000.0);
+    r.rtf = round_to(rtf, 1000000.0);
+    r.text = text;
+    return r;
+}
+
+inline std::string csv_field(const std::string& f) {  // csv crate, QuoteStyle::Necessary
+    bool q = f.empty() ? false : false;
+    for (char c : f)
+        if (c == '"' || c == ',' || c == '\n' || c == '\r') { q = true; break; }
+    if (!q) return f;
+    std::string o = "\"";
+    for (char c : f) { if (c == '"') o += '"'; o += c; }
+    return o + "\"";
+}
+
+inline std::string csv_text(const std::vector<RowOut>& rows) {  // :1215-1229
+    std::string o = "file,duration_s,end_to_end_s,rtf,text\n";
+    char b[64];
+    for (auto& r : rows) {
+        o += csv_field(r.file) + ",";
+        snprintf(b, sizeof b, "%.3f", r.duration_s); o += b; o += ",";
+        snprintf(b, sizeof b, "%.4f", r.end_to_end_s); o += b; o += ",";
+        snprintf(b, sizeof b, "%.6f", r.rtf); o += b; o += ",";
+        o += csv_field(r.text) + "\n";
+    }
+    return o;
+}
+
+inline std::string per_file_json(const std::vector<RowOut>& rows) {  // :1232 to_string_pretty(&rows)
+    if (rows.empty()) return "[]";
+    std::string o = "[\n";
+    for (size_t i = 0; i < rows.size(); i++) {
+        JVal r = JVal::obj(false);  // derived struct: declaration order
+        r.set("file", JVal::str(rows[i].file)).set("duration_s", JVal::num(rows[i].duration_s))
+            .set("end_to_end_s", JVal::num(rows[i].end_to_end_s)).set("rtf", JVal::num(rows[i].rtf))
+            .set("text", JVal::str(rows[i].text));
+        o += "  ";
+        r.write(o, 2);
+        o += (i + 1 < rows.size()) ? ",\n" : "\n";
+    }
+    return o + "]";
+}
+
+struct OrtCfg {  // :91-100 — CPU-EP knobs: accepted and echoed only, they have no GPU analogue
+    long long intra_op = 1, inter_op = 1;
+    std::string execution_mode = "SEQUENTIAL", graph_opt = "ENABLE_ALL";
+    bool cpu_mem_arena = true, mem_pattern = true, allow_spinning = true;
+    JVal json(bool sorted) const {
+        JVal j = JVal::obj(sorted);
+        j.set("intra_op", JVal::integer(intra_op)).set("inter_op", JVal::integer(inter_op))
+            .set("execution_mode", JVal::str(execution_mode)).set("graph_opt", JVal::str(graph_opt))
+            .set("cpu_mem_arena", JVal::boolean(cpu_mem_arena)).set("mem_pattern", JVal::boolean(mem_pattern))
+            .set("allow_spinning", JVal::boolean(allow_spinning));
+        return j;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// audio — src/main.rs:207-316 (WAV container only; FLAC/MP3 are out of scope here)
+// ---------------------------------------------------------------------------------------------
+inline std::vector<float> resample_linear(const std::vector<float>& x, uint32_t sr_in, uint32_t sr_out) {  // :207-226
+    if (sr_in == sr_out) return x;
+    double ratio = (double)sr_out / (double)sr_in;
+    size_t n_out = (size_t)std::llround((double)x.size() * ratio);
+    std::vector<float> y;
+    y.reserve(n_out);
+    for (size_t i = 0; i < n_out; i++) {
+        double t = (double)i / ratio;
+        long long i0 = (long long)std::floor(t), i1 = i0 + 1;
+        double a = t - (double)i0;
+        float s0 = (i0 < 0 || (size_t)i0 >= x.size()) ? 0.0f : x[(size_t)i0];
+        float s1 = (i1 < 0 || (size_t)i1 >= x.size()) ? 0.0f : x[(size_t)i1];
+        y.push_back((float)(1.0 - a) * s0 + (float)a * s1);
+    }
+    return y;
+}
+
+// Decodes PCM WAV (U8 / S16 / IEEE F32), channel-mean downmix (:266-302), resample to 16 kHz.
+inline void load_audio_16k_mono(const std::string& path, std::vector<float>& out, double* dur_s) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("Failed to open audio: " + path);
+    std::vector<unsigned char> d;
+    unsigned char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + n);
+    fclose(f);
+    auto u16 = [&](size_t o) { return (uint32_t)d[o] | ((uint32_t)d[o + 1] << 8); };
+    auto u32 = [&](size_t o) { return u16(o) | (u16(o + 2) << 16); };
+    if (d.size() < 12 || memcmp(d.data(), "RIFF", 4) || memcmp(d.data() + 8, "WAVE", 4))
+        throw std::runtime_error("Unsupported container (only RIFF/WAVE is decoded here): " + path);
+    uint32_t fmt = 0, ch = 0, sr = 0, bits = 0;
+    size_t data_off = 0, data_len = 0, p = 12;
+    while (p + 8 <= d.size()) {
+        uint32_t len = u32(p + 4);
+        if (!memcmp(d.data() + p, "fmt ", 4) && p + 8 + 16 <= d.size()) {
+            fmt = u16(p + 8); ch = u16(p + 10); sr = u32(p + 12); bits = u16(p + 22);
+            if (fmt == 0xFFFE && len >= 26) fmt = u16(p + 8 + 24);  // WAVE_FORMAT_EXTENSIBLE sub-format
+        } else if (!memcmp(d.data() + p, "data", 4)) {
+            data_off = p + 8;
+            data_len = std::min<size_t>(len, d.size() - data_off);
+            break;
+        }
+        p += 8 + len + (len & 1);
+    }
+    if (!sr) throw std::runtime_error("Unknown sample rate");
+    if (!ch) throw std::runtime_error("Unknown channels");
+    std::vector<float> s;
+    const size_t bps = bits / 8, frames = (bps && ch) ? data_len / (bps * ch) : 0;
+    s.reserve(frames);
+    for (size_t i = 0; i < frames; i++) {
+        float acc = 0.0f;
+        for (uint32_t c = 0; c < ch; c++) {
+            size_t o = data_off + (i * ch + c) * bps;
+            if (fmt == 1 && bits == 8) acc += ((float)d[o] - 128.0f) / 128.0f;
+            else if (fmt == 1 && bits == 16) acc += (float)(int16_t)u16(o) / 32768.0f;
+            else if (fmt == 3 && bits == 32) { uint32_t u = u32(o); float v; memcpy(&v, &u, 4); acc += v; }
+            else throw std::runtime_error("Unsupported decoded sample format");  // :303
+        }
+        s.push_back(acc / (float)ch);
+    }
+    if (sr != 16000) s = resample_linear(s, sr, 16000);
+    *dur_s = (double)s.size() / 16000.0;
+    out.swap(s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// tokens — src/main.rs:518-569, 637-657
+// ---------------------------------------------------------------------------------------------
+struct Tokenizer {
+    std::map<std::string, int64_t> special;        // added token content → id
+    std::vector<std::string> id_to_tok;            // vocab
+    std::vector<bool> is_special;
+    bool loaded = false;
+    std::string path;
+};
+
+inline bool load_tokenizer(const std::string& path, Tokenizer& t) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::string txt;
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) txt.append(buf, n);
+    fclose(f);
+    std::string err;
+    auto j = whjson::parse(txt, &err);
+    if (!j) throw std::runtime_error("Failed to load tokenizer " + path + ": " + err);
+    auto grow = [&](size_t id) { if (t.id_to_tok.size() <= id) { t.id_to_tok.resize(id + 1); t.is_special.resize(id + 1, false); } };
+    if (auto m = j->get("model"))
+        if (auto v = m->get("vocab"))
+            for (auto& kv : v->obj) { size_t id = (size_t)kv.second->as_i64(); grow(id); t.id_to_tok[id] = kv.first; }
+    if (auto a = j->get("added_tokens"))
+        for (auto& e : a->arr) {
+            auto c = e->get("content"); auto i = e->get("id"); auto sp = e->get("special");
+            if (!c || !i) continue;
+            size_t id = (size_t)i->as_i64();
+            grow(id);
+            t.id_to_tok[id] = c->str;
+            t.is_special[id] = sp ? sp->b : true;
+            t.special[c->str] = (int64_t)id;
+        }
+    t.loaded = true;
+    t.path = path;
+    return true;
+}
+
+struct WhisperSpecial { int64_t sot, eot, lang, task, no_timestamps; };
+
+inline WhisperSpecial special_tokens(const std::string& language, const std::string& task, const Tokenizer* tok) {
+    if (tok && tok->loaded) {  // :529-541
+        auto get = [&](const std::string& s) {
+            auto it = tok->special.find(s);
+            if (it == tok->special.end()) throw std::runtime_error("Tokenizer missing token: " + s);
+            return it->second;
+        };
+        return {get("<|startoftranscript|>"), get("<|endoftext|>"), get("<|" + language + "|>"), get("<|" + task + "|>"),
+                get("<|notimestamps|>")};
+    }
+    WhisperSpecial s;  // :549-566 hard-coded multilingual ids
+    s.sot = 50258; s.eot = 50257;
+    s.lang = language == "en" ? 50259 : language == "hi" ? 50276 : 50259;
+    s.task = task == "transcribe" ? 50359 : task == "translate" ? 50358 : 50359;
+    s.no_timestamps = 50363;
+    return s;
+}
+
+// GPT-2 byte-level alphabet: unicode code point → byte
+inline const std::map<uint32_t, unsigned char>& byte_decoder() {
+    static std::map<uint32_t, unsigned char> m;
+    if (m.empty()) {
+        std::vector<int> bs;
+        for (int b = '!'; b <= '~'; b++) bs.push_back(b);
+        for (int b = 0xA1; b <= 0xAC; b++) bs.push_back(b);
+        for (int b = 0xAE; b <= 0xFF; b++) bs.push_back(b);
+        std::vector<int> cs = bs;
+        int n = 0;
+        for (int b = 0; b < 256; b++)
+            if (std::find(bs.begin(), bs.end(), b) == bs.end()) { bs.push_back(b); cs.push_back(256 + n++); }
+        for (size_t i = 0; i < bs.size(); i++) m[(uint32_t)cs[i]] = (unsigned char)bs[i];
+    }
+    return m;
+}
+
+inline std::string decode_tokens(const std::vector<int64_t>& tokens, const Tokenizer* tok) {  // :637-648
+    if (tok && tok->loaded) {  // byte-level BPE decode, skip_special_tokens = true
+        std::string joined;
+        for (int64_t t : tokens) {
+            if (t < 0 || (size_t)t >= tok->id_to_tok.size() || tok->is_special[(size_t)t]) continue;
+            joined += tok->id_to_tok[(size_t)t];
+        }
+        std::string bytes;
+        const auto& bd = byte_decoder();
+        for (size_t i = 0; i < joined.size();) {
+            unsigned char c = (unsigned char)joined[i];
+            uint32_t cp; int len;
+            if (c < 0x80) { cp = c; len = 1; }
+            else if ((c >> 5) == 6) { cp = c & 31; len = 2; }
+            else if ((c >> 4) == 14) { cp = c & 15; len = 3; }
+            else { cp = c & 7; len = 4; }
+            for (int k = 1; k < len && i + k < joined.size(); k++) cp = (cp << 6) | ((unsigned char)joined[i + k] & 63);
+            i += (size_t)len;
+            auto it = bd.find(cp);
+            if (it != bd.end()) bytes += (char)it->second;
+        }
+        return bytes;
+    }
+    std::string o = "[TOKENS:";  // :644-647, first 200 ids
+    for (size_t i = 0; i < tokens.size() && i < 200; i++) { if (i) o += " "; o += std::to_string(tokens[i]); }
+    return o + "]";
+}
+
+// ---------------------------------------------------------------------------------------------
+// long-form stitcher — src/main.rs:659-696
+// ---------------------------------------------------------------------------------------------
+inline std::vector<std::string> split_ws(const std::string& s) {
+    std::vector<std::string> w;
+    std::istringstream is(s);
+    std::string t;
+    while (is >> t) w.push_back(t);
+    return w;
+}
+inline std::string lower(std::string s) { for (auto& c : s) c = (char)std::tolower((unsigned char)c); return s; }
+inline std::string trim(const std::string& s) {
+    size_t a = 0, b = s.size();
+    while (a < b && std::isspace((unsigned char)s[a])) a++;
+    while (b > a && std::isspace((unsigned char)s[b - 1])) b--;
+    return s.substr(a, b - a);
+}
+inline size_t word_overlap(const std::string& a, const std::string& b, size_t max_words) {  // :686-696
+    auto aw = split_ws(a), bw = split_ws(b);
+    for (auto& w : aw) w = lower(w);
+    for (auto& w : bw) w = lower(w);
+    size_t mx = std::min(max_words, std::min(aw.size(), bw.size()));
+    for (size_t k = mx; k >= 1; k--) {
+        if (std::equal(aw.end() - (long)k, aw.end(), bw.begin())) return k;
+        if (k == 1) break;
+    }
+    return 0;
+}
+inline std::string stitch_texts(const std::vector<std::string>& chunks) {  // :659-684
+    std::string out;
+    for (auto& chunk : chunks) {
+        std::string t = trim(chunk);
+        if (t.empty()) continue;
+        if (out.empty()) { out = t; continue; }
+        size_t ov = word_overlap(out, t, 16);
+        if (ov > 0) {
+            auto words = split_ws(t);
+            std::string rem;
+            for (size_t i = ov; i < words.size(); i++) { if (!rem.empty()) rem += " "; rem += words[i]; }
+            if (!rem.empty()) { out += " "; out += rem; }
+        } else {
+            out += " ";
+            out += t;
+        }
+    }
+    return out;
+}
+
+}  // namespace whhost

@@ -1,0 +1,81 @@
+// wh_host_capi.cpp — C entry points over wh_host.h so the host logic (statistics, emitters,
+// resampler, stitcher, detokeniser) can be unit-tested from Python without a GPU.
+#include <cstring>
+
+#include "wh_host.h"
+
+using namespace whhost;
+
+static size_t put(const std::string& s, char* out, size_t cap) {
+    if (out && cap) {
+        size_t n = std::min(cap - 1, s.size());
+        memcpy(out, s.data(), n);
+        out[n] = 0;
+    }
+    return s.size();
+}
+
+extern "C" {
+
+size_t whh_fmt_f64(double v, char* out, size_t cap) { return put(fmt_f64(v), out, cap); }
+double whh_percentile(const double* xs, size_t n, double p) { return percentile(std::vector<double>(xs, xs + n), p); }
+void whh_stat_block(const double* xs, size_t n, double* out6) {
+    StatBlock s = stat_block(std::vector<double>(xs, xs + n));
+    out6[0] = s.min; out6[1] = s.median; out6[2] = s.p90; out6[3] = s.p95; out6[4] = s.max; out6[5] = s.mean;
+}
+size_t whh_stat_json(const double* xs, size_t n, char* out, size_t cap) {
+    return put(stat_json(stat_block(std::vector<double>(xs, xs + n))).pretty(), out, cap);
+}
+// rows: files/texts as NUL-separated lists
+static std::vector<RowOut> rows_from(const char* files, const char* texts, const double* dur, const double* e2e, size_t n) {
+    std::vector<RowOut> rows;
+    for (size_t i = 0; i < n; i++) {
+        std::string f(files), t(texts);
+        files += f.size() + 1;
+        texts += t.size() + 1;
+        rows.push_back(make_row(f, dur[i], e2e[i], t));
+    }
+    return rows;
+}
+size_t whh_csv(const char* files, const char* texts, const double* dur, const double* e2e, size_t n, char* out, size_t cap) {
+    return put(csv_text(rows_from(files, texts, dur, e2e, n)), out, cap);
+}
+size_t whh_per_file_json(const char* files, const char* texts, const double* dur, const double* e2e, size_t n, char* out, size_t cap) {
+    return put(per_file_json(rows_from(files, texts, dur, e2e, n)), out, cap);
+}
+size_t whh_resample_linear(const float* x, size_t n, unsigned sr_in, unsigned sr_out, float* out, size_t cap) {
+    std::vector<float> y = resample_linear(std::vector<float>(x, x + n), sr_in, sr_out);
+    if (out) memcpy(out, y.data(), std::min(cap, y.size()) * sizeof(float));
+    return y.size();
+}
+size_t whh_stitch(const char* chunks, size_t n, char* out, size_t cap) {
+    std::vector<std::string> v;
+    for (size_t i = 0; i < n; i++) { std::string c(chunks); chunks += c.size() + 1; v.push_back(c); }
+    return put(stitch_texts(v), out, cap);
+}
+size_t whh_word_overlap(const char* a, const char* b, size_t max_words) { return word_overlap(a, b, max_words); }
+size_t whh_decode_tokens(const long long* toks, size_t n, const char* tokenizer_json, char* out, size_t cap) {
+    Tokenizer t;
+    std::vector<int64_t> v(toks, toks + n);
+    if (tokenizer_json && *tokenizer_json) load_tokenizer(tokenizer_json, t);
+    return put(decode_tokens(v, t.loaded ? &t : nullptr), out, cap);
+}
+int whh_special_tokens(const char* language, const char* task, const char* tokenizer_json, long long* out5) {
+    try {
+        Tokenizer t;
+        if (tokenizer_json && *tokenizer_json) load_tokenizer(tokenizer_json, t);
+        WhisperSpecial s = special_tokens(language, task, t.loaded ? &t : nullptr);
+        out5[0] = s.sot; out5[1] = s.eot; out5[2] = s.lang; out5[3] = s.task; out5[4] = s.no_timestamps;
+        return 0;
+    } catch (...) { return 1; }
+}
+int whh_load_wav(const char* path, float* out, size_t cap, size_t* n, double* dur) {
+    try {
+        std::vector<float> a;
+        load_audio_16k_mono(path, a, dur);
+        *n = a.size();
+        if (out) memcpy(out, a.data(), std::min(cap, a.size()) * sizeof(float));
+        return 0;
+    } catch (...) { return 1; }
+}
+}
