@@ -1,0 +1,66 @@
+// microbench.cpp — isolated timings of the decode kernels (graph-replayed chains of N launches).
+// Build: hipcc --offload-arch=gfx950 -O2 -std=c++17 tools/microbench.cpp -Lwhisper-rust-ort_amd -lwhisper_hip
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <vector>
+#include "../whisper-rust-ort_amd/csrc/wh_kernels.h"
+#include "../include/whisper_hip.h"
+
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static void* dmalloc(size_t b, int fill = 0) { void* p; hipMalloc(&p, b); hipMemset(p, fill, b); return p; }
+
+static double time_chain(hipStream_t s, int reps, const std::function<void()>& launch_once) {
+    launch_once(); hipStreamSynchronize(s);
+    hipGraph_t g; hipGraphExec_t ge;
+    hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    for (int i = 0; i < reps; i++) launch_once();
+    hipStreamEndCapture(s, &g); hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipGraphLaunch(ge, s); hipStreamSynchronize(s);
+    double best = 1e9;
+    for (int r = 0; r < 5; r++) { double t0 = now(); hipGraphLaunch(ge, s); hipStreamSynchronize(s); best = std::min(best, (now() - t0) / reps * 1e6); }
+    hipGraphExecDestroy(ge); hipGraphDestroy(g);
+    return best;
+}
+
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 64;
+    const int d = 512, F = 2048, S = 1500, H = 8, V = 51865;
+    hipStream_t s; hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    const int prec = WH_PREC_BF16;
+    // buffers (bf16 = 2 bytes); contents zero → finite everywhere
+    void* W = dmalloc((size_t)V * d * 2); void* X = dmalloc((size_t)64 * F * 2); float* xres = (float*)dmalloc((size_t)64 * d * 4);
+    float* lnw = (float*)dmalloc(d * 4); float* lnb = (float*)dmalloc(d * 4); float* bias = (float*)dmalloc(F * 4 * 4);
+    void* C1 = dmalloc((size_t)64 * 3 * F * 4); int* pos = (int*)dmalloc(4);
+    for (auto nk : std::vector<std::pair<int, int>>{{512, 512}, {1536, 512}, {2048, 512}, {512, 2048}}) {
+        SkinnyArgs a; a.W = W; a.bias = bias; a.M = B; a.N = nk.first; a.K = nk.second; a.X = X; a.x_mpad = 64;
+        const bool res = nk.first == d;
+        if (res) { a.R = xres; a.ldr = d; a.C = xres; a.ldc = d; } else { a.C = C1; a.c_mpad = 64; }
+        double us = time_chain(s, 200, [&]() { wh_launch_dec_gemm(s, prec, res, a); });
+        printf("dec_gemm M=%d N=%4d K=%4d : %.2f us\n", B, nk.first, nk.second, us);
+    }
+    printf("dec_ln rows=%d : %.2f us\n", B, time_chain(s, 200, [&]() { wh_launch_dec_ln(s, prec, xres, lnw, lnb, X, B, d, 64, nullptr, nullptr, nullptr, 0, nullptr); }));
+    {   // LM head
+        SkinnyArgs a; a.W = W; a.X = X; a.x_mpad = 64; a.M = B; a.N = V; a.K = d; a.pos_p = pos; a.n_prompt = 1;
+        a.mask_first = (unsigned*)dmalloc(V / 8 + 64); a.mask_base = a.mask_first; a.part_val = (float*)dmalloc((size_t)64 * 4096 * 4); a.part_idx = (int*)dmalloc((size_t)64 * 4096 * 4);
+        for (int bpc : {1, 2}) { wh_dbg_lm_blocks_per_cu = bpc; printf("lm_head M=%d blocks/cu=%d : %.2f us\n", B, bpc, time_chain(s, 50, [&]() { wh_launch_lm_head(s, prec, a); })); }
+    }
+    {   // cross attention: distinct K/V planes per "layer" so nothing is cache resident
+        const int L = 6; const size_t plane = (size_t)B * S * d;
+        void* kv = dmalloc(plane * 2 * L * 2); void* q = dmalloc((size_t)B * d * 2); void* out = dmalloc((size_t)B * d * 2);
+        int* tickets = (int*)dmalloc(64 * 4);
+        for (int un : {4, 8}) for (int splits : {1, 2, 4, 8, 16}) {
+            wh_dbg_cross_unroll = un;
+            float* part = (float*)dmalloc((size_t)B * splits * d * 4); float* ml = (float*)dmalloc((size_t)B * splits * H * 2 * 4);
+            int l = 0;
+            double us = time_chain(s, 60, [&]() { wh_launch_dec_cross_attn(s, prec, q, (char*)kv + (size_t)(2 * l) * plane * 2, (char*)kv + (size_t)(2 * l + 1) * plane * 2, part, ml, out, tickets, S, d, H, splits, B, 64); l = (l + 1) % L; });
+            printf("cross_attn B=%d unroll=%d splits=%2d : %.2f us  (%.2f TB/s)\n", B, un, splits, us, 2.0 * S * d * 2 * B / us / 1e6);
+        }
+        void* qkv = dmalloc((size_t)B * 3 * d * 2); void* kc = dmalloc((size_t)B * H * 448 * 64 * 2); void* vc = dmalloc((size_t)B * H * 448 * 64 * 2);
+        int hp = 100; hipMemcpy(pos, &hp, 4, hipMemcpyHostToDevice);
+        printf("self_attn pos=100 : %.2f us\n", time_chain(s, 100, [&]() { wh_launch_dec_self_attn(s, prec, qkv, kc, vc, out, pos, d, H, 448, B, 64); }));
+    }
+    return 0;
+}

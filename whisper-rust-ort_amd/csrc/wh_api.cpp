@@ -271,83 +271,86 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     const int total_pos = P + NEW - 1;
     std::vector<int> done_h(nb);
     // one decoder position = ~50 kernel launches; `emits` adds final LN + LM head + argmax
+    const int mpad = c->mpad;  // row pitch of the k-slab-major decode activations
     auto launch_step = [&](bool emits) {
-            for (int l = 0; l < D.dec_layers; l++) {
-                const DecLayerDev& L = m->dec[l];
+        for (int l = 0; l < D.dec_layers; l++) {
+            const DecLayerDev& L = m->dec[l];
+            SkinnyArgs a;
+            {   // [token + position embedding →] LN1 (slab) → Q|K|V projection
+                Prof pr(c, WH_KG_DEC_OTHER);
+                wh_launch_dec_ln(s, prec, c->dx, L.ln1_w, L.ln1_b, c->dxn, nb, (int)d, mpad, l == 0 ? m->tok_emb : nullptr, m->dec_pos,
+                                 c->feed, ld, c->pos);
+            }
+            {
+                Prof pr(c, WH_KG_DEC_GEMM);
+                a = SkinnyArgs();
+                a.X = c->dxn; a.x_mpad = mpad; a.W = L.qkv_w; a.bias = L.qkv_b; a.C = c->dqkv; a.ldc = 3 * d;
+                a.M = nb; a.N = (int)(3 * d); a.K = (int)d;
+                wh_launch_dec_gemm(s, prec, false, a);
+            }
+            {
+                Prof pr(c, WH_KG_DEC_OTHER);
+                wh_launch_dec_self_attn(s, prec, c->dqkv, (char*)c->self_k + l * cache_l * esz,
+                                        (char*)c->self_v + l * cache_l * esz, c->datt, c->pos, (int)d, D.n_heads,
+                                        D.n_text_ctx, nb, mpad);
+            }
+            {   // self-attention out-proj + residual
+                Prof pr(c, WH_KG_DEC_GEMM);
+                a = SkinnyArgs();
+                a.X = c->datt; a.x_mpad = mpad; a.W = L.o_w; a.bias = L.o_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
+                a.M = nb; a.N = (int)d; a.K = (int)d;
+                wh_launch_dec_gemm(s, prec, true, a);
+            }
+            { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_dec_ln(s, prec, c->dx, L.ln2_w, L.ln2_b, c->dxn, nb, (int)d, mpad, nullptr, nullptr, nullptr, 0, nullptr); }
+            {   // cross-attention query
+                Prof pr(c, WH_KG_DEC_GEMM);
+                a = SkinnyArgs();
+                a.X = c->dxn; a.x_mpad = mpad; a.W = L.cq_w; a.bias = L.cq_b; a.C = c->dq; a.ldc = d; a.M = nb; a.N = (int)d; a.K = (int)d;
+                wh_launch_dec_gemm(s, prec, false, a);
+            }
+            {
+                Prof pr(c, WH_KG_DEC_CROSS_ATTN);
+                wh_launch_dec_cross_attn(s, prec, c->dq, (char*)c->cross_kv + (2 * l) * kv_stride * esz,
+                                         (char*)c->cross_kv + (2 * l + 1) * kv_stride * esz, c->cpart, c->cml, c->datt,
+                                         c->cross_tickets, (int)S, (int)d, D.n_heads, c->cross_splits, nb, mpad);
+            }
+            {   // cross-attention out-proj + residual
+                Prof pr(c, WH_KG_DEC_GEMM);
+                a = SkinnyArgs();
+                a.X = c->datt; a.x_mpad = mpad; a.W = L.co_w; a.bias = L.co_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
+                a.M = nb; a.N = (int)d; a.K = (int)d;
+                wh_launch_dec_gemm(s, prec, true, a);
+            }
+            { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_dec_ln(s, prec, c->dx, L.ln3_w, L.ln3_b, c->dxn, nb, (int)d, mpad, nullptr, nullptr, nullptr, 0, nullptr); }
+            {   // fc1 + GELU (slab output), fc2 + residual
+                Prof pr(c, WH_KG_DEC_GEMM);
+                a = SkinnyArgs();
+                a.X = c->dxn; a.x_mpad = mpad; a.W = L.fc1_w; a.bias = L.fc1_b; a.act = 1; a.C = c->dh; a.c_mpad = mpad;
+                a.M = nb; a.N = (int)F; a.K = (int)d;
+                wh_launch_dec_gemm(s, prec, false, a);
+            }
+            {
+                Prof pr(c, WH_KG_DEC_GEMM);
+                a = SkinnyArgs();
+                a.X = c->dh; a.x_mpad = mpad; a.W = L.fc2_w; a.bias = L.fc2_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
+                a.M = nb; a.N = (int)d; a.K = (int)F;
+                if (!emits && l == D.dec_layers - 1) { a.ticket = c->step_ticket; a.pos_w = c->pos; }  // prompt position: advance here
+                wh_launch_dec_gemm(s, prec, true, a);
+            }
+        }
+        if (emits) {  // final LN + tied LM head + masked argmax; the finish kernel advances the position
+            { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_dec_ln(s, prec, c->dx, m->dec_ln_w, m->dec_ln_b, c->dxn, nb, (int)d, mpad, nullptr, nullptr, nullptr, 0, nullptr); }
+            {
+                Prof pr(c, WH_KG_DEC_GEMM);
                 SkinnyArgs a;
-                {   // [embed +] LN1 + Q|K|V projection
-                    Prof pr(c, WH_KG_DEC_GEMM);
-                    a = SkinnyArgs();
-                    a.W = L.qkv_w; a.bias = L.qkv_b; a.C = c->dqkv; a.ldc = 3 * d;
-                    a.M = nb; a.N = (int)(3 * d); a.K = (int)d;
-                    a.xres = c->dx; a.ln_w = L.ln1_w; a.ln_b = L.ln1_b; a.pos_p = c->pos;
-                    if (l == 0) {
-                        a.xres_out = c->dx; a.tok_emb = m->tok_emb; a.pos_emb = m->dec_pos; a.feed = c->feed; a.feed_ld = ld;
-                    }
-                    wh_launch_dec_gemm(s, prec, false, l == 0 ? 2 : 1, a);
-                }
-                {
-                    Prof pr(c, WH_KG_DEC_OTHER);
-                    wh_launch_dec_self_attn(s, prec, c->dqkv, (char*)c->self_k + l * cache_l * esz,
-                                            (char*)c->self_v + l * cache_l * esz, c->datt, c->pos, (int)d, D.n_heads,
-                                            D.n_text_ctx, nb);
-                }
-                {   // self-attention out-proj + residual
-                    Prof pr(c, WH_KG_DEC_GEMM);
-                    a = SkinnyArgs();
-                    a.X = c->datt; a.ldx = d; a.W = L.o_w; a.bias = L.o_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
-                    a.M = nb; a.N = (int)d; a.K = (int)d;
-                    wh_launch_dec_gemm(s, prec, true, 0, a);
-                }
-                {   // LN2 + cross-attention query
-                    Prof pr(c, WH_KG_DEC_GEMM);
-                    a = SkinnyArgs();
-                    a.W = L.cq_w; a.bias = L.cq_b; a.C = c->dq; a.ldc = d; a.M = nb; a.N = (int)d; a.K = (int)d;
-                    a.xres = c->dx; a.ln_w = L.ln2_w; a.ln_b = L.ln2_b;
-                    wh_launch_dec_gemm(s, prec, false, 1, a);
-                }
-                {
-                    Prof pr(c, WH_KG_DEC_CROSS_ATTN);
-                    wh_launch_dec_cross_attn(s, prec, c->dq, (char*)c->cross_kv + (2 * l) * kv_stride * esz,
-                                             (char*)c->cross_kv + (2 * l + 1) * kv_stride * esz, c->cpart, c->cml, c->datt,
-                                             c->cross_tickets, (int)S, (int)d, D.n_heads, c->cross_splits, nb);
-                }
-                {   // cross-attention out-proj + residual
-                    Prof pr(c, WH_KG_DEC_GEMM);
-                    a = SkinnyArgs();
-                    a.X = c->datt; a.ldx = d; a.W = L.co_w; a.bias = L.co_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
-                    a.M = nb; a.N = (int)d; a.K = (int)d;
-                    wh_launch_dec_gemm(s, prec, true, 0, a);
-                }
-                {   // LN3 + fc1 + GELU, fc2 + residual
-                    Prof pr(c, WH_KG_DEC_GEMM);
-                    a = SkinnyArgs();
-                    a.W = L.fc1_w; a.bias = L.fc1_b; a.act = 1; a.C = c->dh; a.ldc = F; a.M = nb; a.N = (int)F; a.K = (int)d;
-                    a.xres = c->dx; a.ln_w = L.ln3_w; a.ln_b = L.ln3_b;
-                    wh_launch_dec_gemm(s, prec, false, 1, a);
-                }
-                {
-                    Prof pr(c, WH_KG_DEC_GEMM);
-                    a = SkinnyArgs();
-                    a.X = c->dh; a.ldx = F; a.W = L.fc2_w; a.bias = L.fc2_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
-                    a.M = nb; a.N = (int)d; a.K = (int)F;
-                    if (!emits && l == D.dec_layers - 1) { a.ticket = c->step_ticket; a.pos_w = c->pos; }  // prompt position: advance here
-                    wh_launch_dec_gemm(s, prec, true, 0, a);
-                }
+                a.W = m->tok_emb; a.M = nb; a.N = D.vocab; a.K = (int)d;
+                a.X = c->dxn; a.x_mpad = mpad;
+                a.pos_p = c->pos; a.n_prompt = P; a.mask_first = c->mask_first; a.mask_base = c->mask_base;
+                a.logits = d_logits; a.logits_rows = (int)logits_rows; a.part_val = c->part_val; a.part_idx = c->part_idx;
+                wh_launch_lm_head(s, prec, a);
             }
-            if (emits) {  // final LN + tied LM head + masked argmax; the finish kernel advances the position
-                { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_layernorm(s, prec, c->dx, m->dec_ln_w, m->dec_ln_b, c->dxn, nb, (int)d); }
-                {
-                    Prof pr(c, WH_KG_DEC_GEMM);
-                    SkinnyArgs a;
-                    a.W = m->tok_emb; a.M = nb; a.N = D.vocab; a.K = (int)d;
-                    a.X = c->dxn; a.ldx = d;
-                    a.pos_p = c->pos; a.n_prompt = P; a.mask_first = c->mask_first; a.mask_base = c->mask_base;
-                    a.logits = d_logits; a.logits_rows = (int)logits_rows; a.part_val = c->part_val; a.part_idx = c->part_idx;
-                    wh_launch_lm_head(s, prec, a);
-                }
-                { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_argmax_finish(s, c->part_val, c->part_idx, n_tiles, c->pos, c->step_ticket, st, nb); }
-            }
+            { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_argmax_finish(s, c->part_val, c->part_idx, n_tiles, c->pos, c->step_ticket, st, nb); }
+        }
     };
     // Positions 0 .. P-1 (the prompt, the last of which emits the first token) are launched eagerly;
     // the remaining NEW-1 positions replay ONE captured hipGraph of an emitting step — every kernel
@@ -556,8 +559,9 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
     const size_t Ld = D.dec_layers, H = D.n_heads, TC = D.n_text_ctx;
     c->ldv = (int)align_up(S, 64);
     c->tok_ld = D.n_text_ctx + 1;
+    c->mpad = (int)align_up(B, 16);
     // enough workgroups to cover the chip at small batch, no more than 16 key ranges
-    c->cross_splits = (int)std::min<size_t>(32, std::max<size_t>(1, 1024 / B));
+    c->cross_splits = (int)std::min<size_t>(32, std::max<size_t>(1, 256 / B));  // measured: ~256 workgroups streams best
     const size_t n_tiles = (D.vocab + 15) / 16;
     Carver cv;
     const size_t o_pcm = cv.take(B * WH_CLIP_SAMPLES * 4), o_raw = cv.take(B * C * RAW_LD * 4);
@@ -568,8 +572,9 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
     const size_t o_enc = cv.take(B * S * d * esz), o_encf = cv.take(B * S * d * 4);
     const size_t o_ckv = cv.take(Ld * 2 * B * S * d * esz);
     const size_t o_sk = cv.take(Ld * B * H * TC * WH_HEAD_DIM * esz), o_sv = cv.take(Ld * B * H * TC * WH_HEAD_DIM * esz);
-    const size_t o_dx = cv.take(B * d * 4), o_dxn = cv.take(B * d * esz), o_dqkv = cv.take(B * 3 * d * esz);
-    const size_t o_datt = cv.take(B * d * esz), o_dq = cv.take(B * d * esz), o_dh = cv.take(B * F * esz);
+    const size_t MP = align_up(B, 16);  // slab-layout activations: [K/32][MP][32]
+    const size_t o_dx = cv.take(B * d * 4), o_dxn = cv.take(MP * d * esz), o_dqkv = cv.take(B * 3 * d * esz);
+    const size_t o_datt = cv.take(MP * d * esz), o_dq = cv.take(B * d * esz), o_dh = cv.take(MP * F * esz);
     const size_t o_cpart = cv.take(B * c->cross_splits * d * 4), o_cml = cv.take(B * c->cross_splits * H * 2 * 4);
     const size_t o_pv = cv.take(B * n_tiles * 4), o_pi = cv.take(B * n_tiles * 4);
     const size_t o_feed = cv.take(B * c->tok_ld * 4), o_out = cv.take(B * c->tok_ld * 4);

@@ -9,6 +9,7 @@
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(4))) double f64x4;
@@ -69,6 +70,39 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
+}
+
+// Sum over aligned groups of 8 or 16 consecutive lanes with DPP only (no LDS crossbar, no waits):
+// quad_perm[1,0,3,2], quad_perm[2,3,0,1], then row_half_mirror (lane i <-> 7-i pairs the two quads,
+// which already hold equal sums), then row_mirror for 16 lanes.  Every lane ends with the group sum.
+template <int LANES>
+__device__ __forceinline__ float dpp_group_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    if (LANES >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    if (LANES >= 16) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+typedef __attribute__((ext_vector_type(4))) unsigned wh_u32x4;
+// NOTE: hipcc (ROCm 7.2) miscompiles __builtin_bit_cast(bf16x2, <element of a uint vector>) — every
+// element resolves to element 0.  Going through memcpy produces the intended register moves.
+__device__ __forceinline__ bf16x2 as_bf16x2(unsigned u) { bf16x2 r; __builtin_memcpy(&r, &u, 4); return r; }
+template <typename V> __device__ __forceinline__ wh_u32x4 as_u32x4(const V& v) { wh_u32x4 r; __builtin_memcpy(&r, &v, 16); return r; }
+// dot product of 8 packed bf16 pairs (two 16-byte chunks) accumulated into t: 4 x v_dot2c_f32_bf16
+__device__ __forceinline__ float dot8_bf16(wh_u32x4 a, wh_u32x4 b, float t) {
+    t = __builtin_amdgcn_fdot2_f32_bf16(as_bf16x2(a.x), as_bf16x2(b.x), t, false);
+    t = __builtin_amdgcn_fdot2_f32_bf16(as_bf16x2(a.y), as_bf16x2(b.y), t, false);
+    t = __builtin_amdgcn_fdot2_f32_bf16(as_bf16x2(a.z), as_bf16x2(b.z), t, false);
+    t = __builtin_amdgcn_fdot2_f32_bf16(as_bf16x2(a.w), as_bf16x2(b.w), t, false);
+    return t;
+}
+// o0, o1 += p0 * va.{lo,hi} + p1 * vb.{lo,hi} for one packed dword of two keys
+__device__ __forceinline__ void pv2_bf16(unsigned va, unsigned vb, bf16x2 pp, float& o0, float& o1) {
+    const unsigned lo = __builtin_amdgcn_perm(vb, va, 0x05040100u);  // (va.lo, vb.lo)
+    const unsigned hi = __builtin_amdgcn_perm(vb, va, 0x07060302u);  // (va.hi, vb.hi)
+    o0 = __builtin_amdgcn_fdot2_f32_bf16(as_bf16x2(lo), pp, o0, false);
+    o1 = __builtin_amdgcn_fdot2_f32_bf16(as_bf16x2(hi), pp, o1, false);
 }
 
 // order-preserving float <-> uint map for atomicMax on floats of either sign

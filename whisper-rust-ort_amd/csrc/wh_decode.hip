@@ -28,6 +28,10 @@
 #include <mutex>
 #include <unordered_map>
 
+// tuning knobs (tools/microbench.cpp flips them; product code leaves the defaults)
+int wh_dbg_cross_unroll = 4;
+int wh_dbg_lm_blocks_per_cu = 2;
+
 namespace {
 
 // One workgroup arrives; the last one of the grid bumps *pos (every workgroup read *pos at its
@@ -44,161 +48,106 @@ __device__ __forceinline__ void advance_if_last(int* ticket, int* pos_p, int n_b
     }
 }
 
-// Prologue of the decode GEMMs: rows [m0, m0 + rows_tile) of the residual stream (or of the
-// token + position embedding) → LayerNorm → compute dtype → LDS tile Xs[rows_tile][ldx].
-// 16 lanes share a row (lane sub = lane & 15 owns float4 columns sub, sub+16, ...), so one wave
-// instruction covers 4 rows x 256 contiguous bytes; G row groups are loaded before any is reduced.
-// [3P] torch LayerNorm eps 1e-5, biased variance (modeling_whisper.py:371).
-template <typename T, int PRO, int NVR, int G>
-__device__ __forceinline__ void ln_rows_to_lds(const SkinnyArgs& a, int pos, int m0, int rows_tile, int wave, int lane,
-                                               T* Xs, int ldx) {
-    const int sub = lane & 15, rg = lane >> 4, d = a.K;
-    f32x4 lw[NVR], lb[NVR];  // this lane's columns of gamma / beta: loaded once, ahead of everything
+// ---- decode activation layout ("k-slab major") ------------------------------------------------
+// Activations that feed a decode GEMM are stored [K/32][Mpad][32]: the 32-deep k-slab of 16
+// consecutive rows is one contiguous 1 KiB block, so the MFMA column-operand load of a wave (lane
+// (row fl, group fg) reads 8 consecutive k of row 16t+fl) is a single fully coalesced access — the
+// same shape as the weight-fragment loads — instead of 16 rows x 64 B scattered over a row-major
+// [M][K] buffer.  Producers (LayerNorm, attention, fc1 epilogue) write this layout directly.
+__device__ __forceinline__ long slab_idx(int m, int k, int mpad) { return ((long)(k >> 5) * mpad + m) * 32 + (k & 31); }
+
+// LayerNorm of decode rows (f32 residual stream → compute dtype, slab layout); optionally the rows
+// are first formed as token embedding + learned position ([3P] :737, :757-766) and written to x.
+// One wave per row.  [3P] torch LayerNorm eps 1e-5, biased variance (modeling_whisper.py:371).
+template <typename T, bool EMBED>
+__global__ __launch_bounds__(256) void k_dec_ln(float* __restrict__ x, const float* __restrict__ lw,
+                                                const float* __restrict__ lb, T* __restrict__ y, int rows, int d,
+                                                int mpad, const T* __restrict__ tok_emb,
+                                                const float* __restrict__ pos_emb, const int* __restrict__ feed,
+                                                int feed_ld, const int* __restrict__ pos_p) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    constexpr int NV = 5;  // d <= 1280
+    f32x4 v[NV], ww[NV], bb[NV];
+    float* xr = x + (long)row * d;
+    const T* er = nullptr;
+    const float* pr = nullptr;
+    if (EMBED) {
+        const int pos = *pos_p;
+        er = tok_emb + (long)feed[row * feed_ld + pos] * d;
+        pr = pos_emb + (long)pos * d;
+    }
+    float s = 0.0f;
 #pragma unroll
-    for (int j = 0; j < NVR; j++) {
-        const int c = (sub + 16 * j) * 4;
-        lw[j] = lb[j] = f32x4{0, 0, 0, 0};
+    for (int i = 0; i < NV; i++) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = f32x4{0, 0, 0, 0};
         if (c < d) {
-            lw[j] = *reinterpret_cast<const f32x4*>(a.ln_w + c);
-            lb[j] = *reinterpret_cast<const f32x4*>(a.ln_b + c);
+            ww[i] = *reinterpret_cast<const f32x4*>(lw + c);
+            bb[i] = *reinterpret_cast<const f32x4*>(lb + c);
+            if (EMBED) {
+                f32x4 p = *reinterpret_cast<const f32x4*>(pr + c);
+                v[i] = f32x4{cvt_in<T>(er[c]) + p[0], cvt_in<T>(er[c + 1]) + p[1], cvt_in<T>(er[c + 2]) + p[2], cvt_in<T>(er[c + 3]) + p[3]};
+                *reinterpret_cast<f32x4*>(xr + c) = v[i];
+            } else {
+                v[i] = *reinterpret_cast<const f32x4*>(xr + c);
+            }
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
-    for (int p0 = 0; p0 < 4; p0 += G) {
-        f32x4 v[G][NVR];
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.0f;
 #pragma unroll
-        for (int g = 0; g < G; g++) {
-            const int ml = wave * 16 + (p0 + g) * 4 + rg, m = m0 + ml;
-            const bool valid = ml < rows_tile && m < a.M;
-            const float* xr = a.xres + (long)m * d;
-            const T* er = nullptr;
-            const float* pr = nullptr;
-            if (PRO == 2 && valid) {
-                const long tok = a.feed[m * a.feed_ld + pos];
-                er = (const T*)a.tok_emb + tok * d;
-                pr = a.pos_emb + (long)pos * d;
-            }
+    for (int i = 0; i < NV; i++)
+        if ((i * 64 + lane) * 4 < d) {
 #pragma unroll
-            for (int j = 0; j < NVR; j++) {
-                const int c = (sub + 16 * j) * 4;
-                v[g][j] = f32x4{0, 0, 0, 0};
-                if (valid && c < d) {
-                    if (PRO == 1) {
-                        v[g][j] = *reinterpret_cast<const f32x4*>(xr + c);
-                    } else {
-                        f32x4 pp = *reinterpret_cast<const f32x4*>(pr + c);
-                        v[g][j] = f32x4{cvt_in<T>(er[c]) + pp[0], cvt_in<T>(er[c + 1]) + pp[1], cvt_in<T>(er[c + 2]) + pp[2],
-                                        cvt_in<T>(er[c + 3]) + pp[3]};
-                        if (blockIdx.x == 0) *reinterpret_cast<f32x4*>(a.xres_out + (long)m * d + c) = v[g][j];
-                    }
-                }
-            }
+            for (int e = 0; e < 4; e++) { float t = v[i][e] - mean; q += t * t; }
         }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
 #pragma unroll
-        for (int g = 0; g < G; g++) {
-            const int ml = wave * 16 + (p0 + g) * 4 + rg;
-            float sum = 0.0f;
-#pragma unroll
-            for (int j = 0; j < NVR; j++) sum += (v[g][j][0] + v[g][j][1]) + (v[g][j][2] + v[g][j][3]);
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) sum += __shfl_xor(sum, off);
-            const float mean = sum / (float)d;
-            float q = 0.0f;
-#pragma unroll
-            for (int j = 0; j < NVR; j++) {
-                if ((sub + 16 * j) * 4 < d) {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) { float t = v[g][j][e] - mean; q += t * t; }
-                }
-            }
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) q += __shfl_xor(q, off);
-            const float rstd = rsqrtf(q / (float)d + 1e-5f);
-            const bool live = (m0 + ml) < a.M;
-            if (ml < rows_tile) {
-#pragma unroll
-                for (int j = 0; j < NVR; j++) {
-                    const int c = (sub + 16 * j) * 4;
-                    if (c < d) {
-                        const f32x4 ww = lw[j], bb = lb[j];
-                        T* dst = Xs + (long)ml * ldx + c;
-                        if (live)
-                            store4(dst, (v[g][j][0] - mean) * rstd * ww[0] + bb[0], (v[g][j][1] - mean) * rstd * ww[1] + bb[1],
-                                   (v[g][j][2] - mean) * rstd * ww[2] + bb[2], (v[g][j][3] - mean) * rstd * ww[3] + bb[3]);
-                        else
-                            store4(dst, 0.0f, 0.0f, 0.0f, 0.0f);
-                    }
-                }
-            }
-        }
+    for (int i = 0; i < NV; i++) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d)
+            store4(y + slab_idx(row, c, mpad), (v[i][0] - mean) * rstd * ww[i][0] + bb[i][0], (v[i][1] - mean) * rstd * ww[i][1] + bb[i][1],
+                   (v[i][2] - mean) * rstd * ww[i][2] + bb[i][2], (v[i][3] - mean) * rstd * ww[i][3] + bb[i][3]);
     }
 }
 
-// ---- decode GEMM: C[m][n] = act(sum_k X[m][k] W[n][k] + bias[n]) (+ R[m][n]),  M <= 64 ---------
-// Weight-streaming: every weight element is read once per launch straight into MFMA fragments
-// (up to 8 fragments per wave in flight before the first MFMA); activations are MFMA column
-// operands.
-//   PRO 0: X[m][:] read from global (compute dtype).
-//   PRO 1: X = LayerNorm(x f32) computed in the prologue into LDS.
-//   PRO 2: x = tok_emb[feed[m][pos]] + pos_emb[pos] (workgroup 0 also writes x), then as PRO 1.
-//   SPLITK=4: one 16-column tile per workgroup, the four waves split K and reduce through LDS.
-//   SPLITK=1: four 16-column tiles per workgroup, one per wave (LM head, N = vocab).
-//   MODE 0  : normal epilogue.   MODE 1: LM-head epilogue — optional logits store + per-tile
-//             masked argmax partials (reference argmax_last_dim_raw, src/main.rs:709-735).
-template <typename T, typename TO, int MT, int SPLITK, int PRO, int MODE>
-__global__ __launch_bounds__(256) void k_dec_gemm(SkinnyArgs a) {
+// ---- decode GEMM: C[m][n] = act(sum_k X[m][k] W[n][k] + bias[n]) (+ R[m][n]),  M <= 64 per row group
+// Weight-streaming: every weight element is read once per launch straight into MFMA fragments (up
+// to 8 per wave in flight before the first MFMA); activations are read as MFMA column operands from
+// the slab layout.  The waves of a workgroup split K (4 or 8 ways) and reduce through LDS; wave w
+// then finishes row-tile w (bias, erf-GELU, f32 residual; output row-major or slab).
+template <typename T, typename TO, int MT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fl = lane & 15, fg = lane >> 4;
-    const int tile = (SPLITK == 4) ? blockIdx.x : blockIdx.x * 4 + wave;
-    const int n_tiles = (a.N + 15) >> 4;
-    const bool tile_ok = tile < n_tiles;
-    const int n0 = tile * 16;
-    const T* W = (const T*)a.W;
+    const int n0 = blockIdx.x * 16;
+    const int m0 = blockIdx.y * MT * 16;  // first row of this workgroup's row group
     int nrow = n0 + fl;
     if (nrow > a.N - 1) nrow = a.N - 1;
-    const int kspan = a.K / SPLITK;
-    const int kb = (SPLITK == 4) ? wave * kspan : 0;
-    const T* wp = W + (long)nrow * a.K + kb + fg * 8;
-    const int iters = kspan >> 5;
-
-    // first chunk of weight fragments goes in flight before anything else
+    const int kspan = a.K / NW, kb = wave * kspan, iters = kspan >> 5;
+    const T* wp = (const T*)a.W + (long)nrow * a.K + kb + fg * 8;
+    const T* xp = (const T*)a.X + ((long)(kb >> 5) * a.x_mpad + m0 + fl) * 32 + fg * 8;
+    const long xstep = (long)a.x_mpad * 32;
     constexpr int DEPTH = 8;
-    typename FragT<T>::type wq[DEPTH];
+    typename FragT<T>::type wq[DEPTH], xq[DEPTH][MT];
 #pragma unroll
     for (int i = 0; i < DEPTH; i++)
-        if (i < iters) wq[i] = load_frag<T>(wp + i * 32);
-
-    const int pos = a.pos_p ? *a.pos_p : 0;
-    const int m0 = blockIdx.y * MT * 16;  // first row of this workgroup's row group
-    // epilogue operands of the SPLITK=4 form (wave w finishes row-tile w): fetched now, used last
-    f32x4 pre_bias = {0, 0, 0, 0}, pre_r = {0, 0, 0, 0};
-    if (SPLITK == 4 && wave < MT) {
-        const int n = n0 + 4 * fg, m = m0 + wave * 16 + fl;
-        if (n < a.N && m < a.M) {
-            if (a.bias) pre_bias = *reinterpret_cast<const f32x4*>(a.bias + n);
-            if (a.R) pre_r = *reinterpret_cast<const f32x4*>(a.R + (long)m * a.ldr + n);
-        }
-    }
-    const int ldx = (PRO == 0) ? (int)a.ldx : a.K + 8;
-    const T* X;
-    if constexpr (PRO == 0) {
-        X = (const T*)a.X;
-    } else {
-        T* Xs = reinterpret_cast<T*>(smem_raw);
-        if (a.K <= 512) ln_rows_to_lds<T, PRO, 8, 2>(a, pos, m0, MT * 16, wave, lane, Xs, ldx);
-        else ln_rows_to_lds<T, PRO, 20, 1>(a, pos, m0, MT * 16, wave, lane, Xs, ldx);
-        __syncthreads();
-        X = Xs;
-    }
-    const T* xp[MT];
+        if (i < iters) {
+            wq[i] = load_frag<T>(wp + i * 32);
 #pragma unroll
-    for (int t = 0; t < MT; t++) {
-        int m = t * 16 + fl;  // row within the LDS tile (PRO != 0) or global row (PRO == 0)
-        if (PRO == 0) {
-            m += m0;
-            if (m > a.M - 1) m = a.M - 1;
+            for (int t = 0; t < MT; t++) xq[i][t] = load_frag<T>(xp + i * xstep + t * 512);
         }
-        xp[t] = X + (long)m * ldx + kb + fg * 8;
+    // epilogue operands (wave w finishes row-tile w): fetched now, used last
+    f32x4 pre_bias = {0, 0, 0, 0}, pre_r = {0, 0, 0, 0};
+    const int en = n0 + 4 * fg, em = m0 + wave * 16 + fl;
+    const bool ep_ok = wave < MT && en < a.N && em < a.M;
+    if (ep_ok) {
+        if (a.bias) pre_bias = *reinterpret_cast<const f32x4*>(a.bias + en);
+        if (a.R) pre_r = *reinterpret_cast<const f32x4*>(a.R + (long)em * a.ldr + en);
     }
     f32x4 acc[MT];
 #pragma unroll
@@ -207,102 +156,41 @@ __global__ __launch_bounds__(256) void k_dec_gemm(SkinnyArgs a) {
         if (c0 > 0) {
 #pragma unroll
             for (int i = 0; i < DEPTH; i++)
-                if (c0 + i < iters) wq[i] = load_frag<T>(wp + (c0 + i) * 32);
+                if (c0 + i < iters) {
+                    wq[i] = load_frag<T>(wp + (c0 + i) * 32);
+#pragma unroll
+                    for (int t = 0; t < MT; t++) xq[i][t] = load_frag<T>(xp + (c0 + i) * xstep + t * 512);
+                }
         }
 #pragma unroll
-        for (int i = 0; i < DEPTH; i++) {
+        for (int i = 0; i < DEPTH; i++)
             if (c0 + i < iters) {
 #pragma unroll
-                for (int t = 0; t < MT; t++) {
-                    typename FragT<T>::type xf = load_frag<T>(xp[t] + (c0 + i) * 32);
-                    mma16(acc[t], wq[i], xf);  // D rows = n (4*fg + r), col = m (fl)
-                }
+                for (int t = 0; t < MT; t++) mma16(acc[t], wq[i], xq[i][t]);  // D rows = n (4*fg + r), col = m (fl)
             }
-        }
     }
-    if (SPLITK == 4) {
-        // cross-wave K reduction; wave w then owns row-tile w of the epilogue
-        f32x4* red = reinterpret_cast<f32x4*>(smem_raw + ((PRO == 0) ? 0 : (size_t)MT * 16 * ldx * sizeof(T)));
+    f32x4* red = reinterpret_cast<f32x4*>(smem_raw);
 #pragma unroll
-        for (int t = 0; t < MT; t++) red[(wave * MT + t) * 64 + lane] = acc[t];
-        __syncthreads();
-        if (wave < MT) {
-            f32x4 s = red[(0 * MT + wave) * 64 + lane];
+    for (int t = 0; t < MT; t++) red[(wave * MT + t) * 64 + lane] = acc[t];
+    __syncthreads();
+    if (ep_ok) {
+        f32x4 s = red[(0 * MT + wave) * 64 + lane];
 #pragma unroll
-            for (int w = 1; w < 4; w++) {
-                f32x4 o = red[(w * MT + wave) * 64 + lane];
-                s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
-            }
-            const int n = n0 + 4 * fg, m = m0 + wave * 16 + fl;
-            if (n < a.N && m < a.M) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    v[e] = s[e] + pre_bias[e];
-                    if (a.act == 1) v[e] = gelu_erf(v[e]);
-                    v[e] += pre_r[e];
-                }
-                store4((TO*)a.C + (long)m * a.ldc + n, v[0], v[1], v[2], v[3]);
-            }
+        for (int w = 1; w < NW; w++) {
+            f32x4 o = red[(w * MT + wave) * 64 + lane];
+            s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
         }
-        advance_if_last(a.ticket, a.pos_w, gridDim.x * gridDim.y);
-        return;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            v[e] = s[e] + pre_bias[e];
+            if (a.act == 1) v[e] = gelu_erf(v[e]);
+            v[e] += pre_r[e];
+        }
+        TO* dst = a.c_mpad ? (TO*)a.C + slab_idx(em, en, a.c_mpad) : (TO*)a.C + (long)em * a.ldc + en;
+        store4(dst, v[0], v[1], v[2], v[3]);
     }
-    // SPLITK == 1
-    const int n = n0 + 4 * fg;
-    if (MODE == 0) {
-        if (tile_ok && n < a.N) {
-            f32x4 bias = {0, 0, 0, 0};
-            if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + n);
-#pragma unroll
-            for (int t = 0; t < MT; t++) {
-                const int m = m0 + t * 16 + fl;
-                if (m >= a.M) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    v[e] = acc[t][e] + bias[e];
-                    if (a.act == 1) v[e] = gelu_erf(v[e]);
-                }
-                if (a.R) {
-                    f32x4 r = *reinterpret_cast<const f32x4*>(a.R + (long)m * a.ldr + n);
-                    v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
-                }
-                store4((TO*)a.C + (long)m * a.ldc + n, v[0], v[1], v[2], v[3]);
-            }
-        }
-        advance_if_last(a.ticket, a.pos_w, gridDim.x * gridDim.y);
-    } else if (tile_ok) {
-        const int gen = pos - (a.n_prompt - 1);  // index of the token this row generates
-        const unsigned* mask = (gen == 0) ? a.mask_first : a.mask_base;
-#pragma unroll
-        for (int t = 0; t < MT; t++) {
-            const int m = m0 + t * 16 + fl;
-            float bv = -INFINITY;
-            int bi = 0x7fffffff;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int nn = n + e;
-                const float v = acc[t][e];
-                if (nn < a.N && m < a.M) {
-                    if (a.logits && gen >= 0 && gen < a.logits_rows)
-                        a.logits[((long)m * a.logits_rows + gen) * a.N + nn] = v;
-                    const bool sup = (mask[nn >> 5] >> (nn & 31)) & 1u;
-                    if (!sup && v > bv) { bv = v; bi = nn; }  // strict >, NaN never wins
-                }
-            }
-#pragma unroll
-            for (int off = 16; off < 64; off <<= 1) {
-                float ov = __shfl_xor(bv, off);
-                int oi = __shfl_xor(bi, off);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
-            if (fg == 0 && m < a.M) {
-                a.part_val[(long)m * n_tiles + tile] = bv;
-                a.part_idx[(long)m * n_tiles + tile] = bi;
-            }
-        }
-    }
+    advance_if_last(a.ticket, a.pos_w, gridDim.x * gridDim.y);
 }
 
 // ---- LM head: logits = LN(x) · E^T over the whole vocabulary ([3P] :790, :965-970) + masked argmax
@@ -318,46 +206,56 @@ __global__ __launch_bounds__(256) void k_lm_head(SkinnyArgs a) {
     const int fl = lane & 15, fg = lane >> 4;
     const int n_tiles = (a.N + 15) >> 4;
     const int m0 = blockIdx.y * MT * 16;
-    const int ldx = a.K + 8;
+    // activation tile: the row group's rows of every k-slab, LDS layout [K/32][MT*16][32]
     T* Xs = reinterpret_cast<T*>(smem_raw);
-    const int cpr = a.K / EPC;
-    for (int c = tid; c < MT * 16 * cpr; c += 256) {
-        const int row = c / cpr, col = (c - row * cpr) * EPC;
-        u32x4 val = {0, 0, 0, 0};
-        if (m0 + row < a.M) val = *reinterpret_cast<const u32x4*>((const T*)a.X + (long)(m0 + row) * a.ldx + col);
-        *reinterpret_cast<u32x4*>(Xs + (long)row * ldx + col) = val;
+    constexpr int ROWS = MT * 16;
+    const int nslab = a.K >> 5, cps = ROWS * 32 / EPC;  // 16-B chunks per slab of this row group
+    for (int c = tid; c < nslab * cps; c += 256) {
+        const int sl = c / cps, o = (c - sl * cps) * EPC;
+        *reinterpret_cast<u32x4*>(Xs + (long)sl * ROWS * 32 + o) =
+            *reinterpret_cast<const u32x4*>((const T*)a.X + ((long)sl * a.x_mpad + m0) * 32 + o);
     }
     const int pos = *a.pos_p;
     const int gen = pos - (a.n_prompt - 1);  // index of the token this row generates
     const unsigned* mask = (gen == 0) ? a.mask_first : a.mask_base;
-    __syncthreads();
+    // Pipeline unit = (tile, 16-fragment chunk of K).  Two register sets: the next unit's weight
+    // fragments are in flight while the current unit's MFMAs issue.
     const int iters = a.K >> 5;
-    constexpr int DEPTH = 8;
-    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
-        const int n0 = tile * 16;
-        int nrow = n0 + fl;
+    constexpr int DEPTH = 16;
+    const int nchunk = (iters + DEPTH - 1) / DEPTH;
+    const int stride = gridDim.x * 4, first = blockIdx.x * 4 + wave;
+    const int my_tiles = first < n_tiles ? (n_tiles - first + stride - 1) / stride : 0;
+    const int units = my_tiles * nchunk;
+    typedef typename FragT<T>::type frag_t;
+    frag_t wA[DEPTH], wB[DEPTH];
+    f32x4 acc[MT];
+    auto load_unit = [&](frag_t (&wq)[DEPTH], int u) {
+        const int tile = first + (u / nchunk) * stride, c0 = (u % nchunk) * DEPTH;
+        int nrow = tile * 16 + fl;
         if (nrow > a.N - 1) nrow = a.N - 1;
         const T* wp = (const T*)a.W + (long)nrow * a.K + fg * 8;
-        f32x4 acc[MT];
 #pragma unroll
-        for (int t = 0; t < MT; t++) acc[t] = f32x4{0, 0, 0, 0};
-        for (int c0 = 0; c0 < iters; c0 += DEPTH) {
-            typename FragT<T>::type wq[DEPTH];
+        for (int i = 0; i < DEPTH; i++)
+            if (c0 + i < iters) wq[i] = load_frag<T>(wp + (c0 + i) * 32);
+    };
+    auto compute_unit = [&](const frag_t (&wq)[DEPTH], int u) {
+        const int tile = first + (u / nchunk) * stride, ck = u % nchunk, c0 = ck * DEPTH;
+        if (ck == 0) {
 #pragma unroll
-            for (int i = 0; i < DEPTH; i++)
-                if (c0 + i < iters) wq[i] = load_frag<T>(wp + (c0 + i) * 32);
+            for (int t = 0; t < MT; t++) acc[t] = f32x4{0, 0, 0, 0};
+        }
 #pragma unroll
-            for (int i = 0; i < DEPTH; i++) {
-                if (c0 + i < iters) {
+        for (int i = 0; i < DEPTH; i++) {
+            if (c0 + i < iters) {
 #pragma unroll
-                    for (int t = 0; t < MT; t++) {
-                        typename FragT<T>::type xf = load_frag<T>(Xs + (long)(t * 16 + fl) * ldx + (c0 + i) * 32 + fg * 8);
-                        mma16(acc[t], wq[i], xf);
-                    }
+                for (int t = 0; t < MT; t++) {
+                    frag_t xf = load_frag<T>(Xs + ((long)(c0 + i) * ROWS + t * 16 + fl) * 32 + fg * 8);
+                    mma16(acc[t], wq[i], xf);
                 }
             }
         }
-        const int n = n0 + 4 * fg;
+        if (ck != nchunk - 1) return;
+        const int n = tile * 16 + 4 * fg;
 #pragma unroll
         for (int t = 0; t < MT; t++) {
             const int m = m0 + t * 16 + fl;
@@ -384,6 +282,17 @@ __global__ __launch_bounds__(256) void k_lm_head(SkinnyArgs a) {
                 a.part_val[(long)m * n_tiles + tile] = bv;
                 a.part_idx[(long)m * n_tiles + tile] = bi;
             }
+        }
+    };
+    if (units > 0) load_unit(wA, 0);   // in flight while the activation tile is staged
+    __syncthreads();
+    for (int u = 0; u < units; u += 2) {
+        const bool hasB = u + 1 < units;
+        if (hasB) load_unit(wB, u + 1);
+        compute_unit(wA, u);
+        if (hasB) {
+            if (u + 2 < units) load_unit(wA, u + 2);
+            compute_unit(wB, u + 1);
         }
     }
 }
@@ -444,7 +353,8 @@ __global__ __launch_bounds__(256) void k_argmax_finish(const float* __restrict__
 template <typename T>
 __global__ __launch_bounds__(64) void k_dec_self_attn(const T* __restrict__ qkv, T* __restrict__ kc,
                                                       T* __restrict__ vc, T* __restrict__ out,
-                                                      const int* __restrict__ pos_p, int d, int n_heads, int tc) {
+                                                      const int* __restrict__ pos_p, int d, int n_heads, int tc,
+                                                      int mpad) {
     constexpr int HD = WH_HEAD_DIM;
     __shared__ float qs[HD];
     __shared__ float sc[512];
@@ -492,7 +402,7 @@ __global__ __launch_bounds__(64) void k_dec_self_attn(const T* __restrict__ qkv,
         o0 += sc[j] * v0; o1 += sc[j + 1] * v1; o2 += sc[j + 2] * v2; o3 += sc[j + 3] * v3;
     }
     for (; j < pos; j++) o0 += sc[j] * cvt_in<T>(vcb[(long)j * HD + lane]);
-    out[(long)b * d + h * HD + lane] = cvt_out<T>(((o0 + o1) + (o2 + o3)) / sum);
+    out[slab_idx(b, h * HD + lane, mpad)] = cvt_out<T>(((o0 + o1) + (o2 + o3)) / sum);
 }
 
 // ---- decoder cross-attention, one position ([3P] :433-440, 478-491) -----------------------------
@@ -505,34 +415,38 @@ __global__ __launch_bounds__(64) void k_dec_self_attn(const T* __restrict__ qkv,
 // acquire around an arrival ticket) and writes the attention output.
 //   ck/cv: [B][S][d]  (head h at columns h*64..h*64+63),   q: [B][d] pre-scaled
 //   part : [B][splits][d] unnormalised partial outputs, ml: [B][splits][H][2] (max, sum)
-template <typename T, int NCH>  // NCH = ceil(d*sizeof(T)/16 / 64): 16-B chunks per lane per row
+template <typename T, int NCH, int UNROLL>  // NCH = ceil(d*sizeof(T)/16 / 64): 16-B chunks per lane per row
 __global__ __launch_bounds__(256) void k_dec_cross_attn(const T* __restrict__ q, const T* __restrict__ ck,
                                                         const T* __restrict__ cv, float* __restrict__ part,
                                                         float* __restrict__ ml, T* __restrict__ out,
                                                         int* __restrict__ tickets, int S, int d, int n_heads,
-                                                        int splits) {
+                                                        int splits, int mpad) {
     constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-B chunk: 8 (bf16) / 4 (f32)
     constexpr int LPH = WH_HEAD_DIM / EPC;     // lanes per head: 8 / 16
-    constexpr int UNROLL = (NCH == 1) ? 4 : (NCH <= 3 ? 2 : 1);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef __attribute__((ext_vector_type(EPC))) T vec_t;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sp = blockIdx.x, b = blockIdx.y;
     const int per = (S + splits - 1) / splits;
     const int ks = sp * per, ke = min(S, ks + per);
-    const int pw = (ke - ks + 3) >> 2;         // keys per wave, contiguous
-    const int j0 = ks + wave * pw, j1 = min(ke, j0 + pw);
+    // Key groups of UNROLL consecutive keys are dealt round-robin to the four waves, so at any moment
+    // the workgroup reads 4*UNROLL adjacent key rows (one 16 KiB run of K and one of V for bf16 base).
+    const int j1 = ke;
     const int chunks = d / EPC;                // 16-B chunks per row
 
+    constexpr bool PACKED = sizeof(T) == 2;  // bf16: packed-pair arithmetic (v_dot2c_f32_bf16, v_perm_b32)
     float qv[NCH][EPC], o[NCH][EPC], mrun[NCH], lrun[NCH];
+    wh_u32x4 qd[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
         const int ch = lane + 64 * c;
         mrun[c] = -INFINITY;
         lrun[c] = 0.0f;
+        qd[c] = wh_u32x4{0, 0, 0, 0};
+        if (PACKED && ch < chunks) qd[c] = *reinterpret_cast<const wh_u32x4*>(q + (long)b * d + ch * EPC);
 #pragma unroll
         for (int u = 0; u < EPC; u++) {
-            qv[c][u] = (ch < chunks) ? cvt_in<T>(q[(long)b * d + ch * EPC + u]) : 0.0f;
+            qv[c][u] = (!PACKED && ch < chunks) ? cvt_in<T>(q[(long)b * d + ch * EPC + u]) : 0.0f;
             o[c][u] = 0.0f;
         }
     }
@@ -565,11 +479,14 @@ __global__ __launch_bounds__(256) void k_dec_cross_attn(const T* __restrict__ q,
             for (int u = 0; u < UNROLL; u++) {
                 float t = 0.0f;
                 if (ch < chunks) {
+                    if constexpr (PACKED) {  // 4 x v_dot2c_f32_bf16 on the packed pairs, no conversions
+                        t = dot8_bf16(as_u32x4(kk[u][c]), qd[c], t);
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < EPC; e++) t += qv[c][e] * (float)kk[u][c][e];
+                        for (int e = 0; e < EPC; e++) t += qv[c][e] * (float)kk[u][c][e];
+                    }
                 }
-#pragma unroll
-                for (int off = 1; off < LPH; off <<= 1) t += __shfl_xor(t, off);
+                t = dpp_group_sum<LPH>(t);  // every lane of the head's lane group gets the full dot product
                 s[u] = (j + u < j1) ? t : -INFINITY;
                 mx = fmaxf(mx, s[u]);
             }
@@ -577,27 +494,47 @@ __global__ __launch_bounds__(256) void k_dec_cross_attn(const T* __restrict__ q,
             float ls = lrun[c] * scale;
 #pragma unroll
             for (int e = 0; e < EPC; e++) o[c][e] *= scale;
+            if constexpr (PACKED && (UNROLL % 2 == 0)) {
+                // P·V two keys at a time: pair the same element of both keys with v_perm_b32, then one
+                // v_dot2c_f32_bf16 against the packed (p_u, p_u+1) per output element
 #pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                const float p = __expf(s[u] - mx);
-                ls += p;
-                if (ch < chunks) {
+                for (int u = 0; u < UNROLL; u += 2) {
+                    const float p0 = __expf(s[u] - mx), p1 = __expf(s[u + 1] - mx);
+                    ls += p0 + p1;
+                    const bf16x2 pp = bf16x2{(bf16)p0, (bf16)p1};
+                    if (ch < chunks) {
+                        const wh_u32x4 va = as_u32x4(vv[u][c]), vb = as_u32x4(vv[u + 1][c]);
+                        pv2_bf16(va.x, vb.x, pp, o[c][0], o[c][1]);
+                        pv2_bf16(va.y, vb.y, pp, o[c][2], o[c][3]);
+                        pv2_bf16(va.z, vb.z, pp, o[c][4], o[c][5]);
+                        pv2_bf16(va.w, vb.w, pp, o[c][6], o[c][7]);
+                    }
+                }
+            } else {
 #pragma unroll
-                    for (int e = 0; e < EPC; e++) o[c][e] += p * (float)vv[u][c][e];
+                for (int u = 0; u < UNROLL; u++) {
+                    const float p = __expf(s[u] - mx);
+                    ls += p;
+                    if (ch < chunks) {
+#pragma unroll
+                        for (int e = 0; e < EPC; e++) o[c][e] += p * (float)vv[u][c][e];
+                    }
                 }
             }
             mrun[c] = mx;
             lrun[c] = ls;
         }
     };
+    constexpr int GS = 4 * UNROLL;             // stride between this wave's consecutive key groups
+    const int j0 = ks + wave * UNROLL;
     if (j0 < j1) load_set(kA, vA, j0);
-    for (int j = j0; j < j1; j += 2 * UNROLL) {
-        const bool hasB = j + UNROLL < j1;
-        if (hasB) load_set(kB, vB, j + UNROLL);
+    for (int j = j0; j < j1; j += 2 * GS) {
+        const bool hasB = j + GS < j1;
+        if (hasB) load_set(kB, vB, j + GS);
         compute_set(kA, vA, j);
         if (hasB) {
-            if (j + 2 * UNROLL < j1) load_set(kA, vA, j + 2 * UNROLL);
-            compute_set(kB, vB, j + UNROLL);
+            if (j + 2 * GS < j1) load_set(kA, vA, j + 2 * GS);
+            compute_set(kB, vB, j + GS);
         }
     }
     // merge the four waves of this key range (LDS): wm/wl [4][H], wo [4][d]
@@ -678,7 +615,7 @@ __global__ __launch_bounds__(256) void k_dec_cross_attn(const T* __restrict__ q,
             num += w * pv[s2];
             den += w * lv[s2];
         }
-        out[(long)b * d + n] = cvt_out<T>(num / den);
+        out[slab_idx(b, n, mpad)] = cvt_out<T>(num / den);
     }
 }
 
@@ -696,63 +633,59 @@ void set_max_smem(K kernel, size_t bytes) {
     }
 }
 
-template <typename T, typename TO, int SPLITK, int PRO, int MODE>
+template <typename T, typename TO, int NW>
 void launch_dec_gemm_mt(hipStream_t s, const SkinnyArgs& a) {
     const int n_tiles = (a.N + 15) / 16;
-    int mt = std::min(4, (a.M + 15) / 16);
-    auto lds = [&](int t) {
-        return ((PRO == 0) ? 0 : (size_t)t * 16 * (a.K + 8) * sizeof(T)) + (SPLITK == 4 ? (size_t)4 * t * 64 * 16 : 0);
-    };
-    while (mt > 1 && lds(mt) > 150 * 1024) mt--;  // row groups along grid.y when the tile would not fit LDS
-    const size_t sm = lds(mt);
-    dim3 grid(SPLITK == 4 ? n_tiles : (n_tiles + 3) / 4, (a.M + 16 * mt - 1) / (16 * mt));
-#define WH_LAUNCH(MT_)                                                                        \
-    {                                                                                         \
-        auto kfn = k_dec_gemm<T, TO, MT_, SPLITK, PRO, MODE>;                                 \
-        set_max_smem(kfn, sm);                                                                \
-        hipLaunchKernelGGL(kfn, grid, dim3(256), sm, s, a);                                   \
-    }
+    const int mt = std::min(4, (a.M + 15) / 16);
+    const size_t sm = (size_t)NW * mt * 64 * 16;
+    dim3 grid(n_tiles, (a.M + 16 * mt - 1) / (16 * mt));
     switch (mt) {
-        case 1: WH_LAUNCH(1) break;
-        case 2: WH_LAUNCH(2) break;
-        case 3: WH_LAUNCH(3) break;
-        default: WH_LAUNCH(4) break;
+        case 1: hipLaunchKernelGGL((k_dec_gemm<T, TO, 1, NW>), grid, dim3(NW * 64), sm, s, a); break;
+        case 2: hipLaunchKernelGGL((k_dec_gemm<T, TO, 2, NW>), grid, dim3(NW * 64), sm, s, a); break;
+        case 3: hipLaunchKernelGGL((k_dec_gemm<T, TO, 3, NW>), grid, dim3(NW * 64), sm, s, a); break;
+        default: hipLaunchKernelGGL((k_dec_gemm<T, TO, 4, NW>), grid, dim3(NW * 64), sm, s, a); break;
     }
-#undef WH_LAUNCH
 }
 
-template <typename T, typename TO, int PRO>
+template <typename T, typename TO>
 void launch_dec_gemm_split(hipStream_t s, const SkinnyArgs& a) {
-    const bool split = (a.K % 128 == 0) && a.N < 8192;
-    if (split) launch_dec_gemm_mt<T, TO, 4, PRO, 0>(s, a);
-    else launch_dec_gemm_mt<T, TO, 1, PRO, 0>(s, a);
+    // K is split over the waves of a workgroup: 8 ways when it is deep, else 4 (K % 128 == 0 always
+    // holds: d_model and ffn are multiples of 128, checked at model load)
+    if (a.K >= 2048 && a.K % 256 == 0) launch_dec_gemm_mt<T, TO, 8>(s, a);
+    else launch_dec_gemm_mt<T, TO, 4>(s, a);
 }
 
 }  // namespace
 
-// pro: 0 = X from global, 1 = fused LayerNorm of a.xres, 2 = fused embedding + LayerNorm
-void wh_launch_dec_gemm(hipStream_t s, int prec, bool out_f32, int pro, const SkinnyArgs& a) {
-#define WH_PRO(T_, TO_)                                             \
-    switch (pro) {                                                  \
-        case 0: launch_dec_gemm_split<T_, TO_, 0>(s, a); break;     \
-        case 1: launch_dec_gemm_split<T_, TO_, 1>(s, a); break;     \
-        default: launch_dec_gemm_split<T_, TO_, 2>(s, a); break;    \
+void wh_launch_dec_gemm(hipStream_t s, int prec, bool out_f32, const SkinnyArgs& a) {
+    if (prec == WH_PREC_F32) launch_dec_gemm_split<float, float>(s, a);
+    else if (out_f32) launch_dec_gemm_split<bf16, float>(s, a);
+    else launch_dec_gemm_split<bf16, bf16>(s, a);
+}
+
+// x (f32 rows) → LayerNorm → y (compute dtype, slab layout).  tok_emb != nullptr: the rows are first
+// formed as token embedding + position and written to x.
+void wh_launch_dec_ln(hipStream_t s, int prec, float* x, const float* lw, const float* lb, void* y, int rows, int d, int mpad,
+                      const void* tok_emb, const float* pos_emb, const int* feed, int feed_ld, const int* pos_p) {
+    dim3 grid((rows + 3) / 4);
+    if (prec == WH_PREC_F32) {
+        if (tok_emb) hipLaunchKernelGGL((k_dec_ln<float, true>), grid, dim3(256), 0, s, x, lw, lb, (float*)y, rows, d, mpad, (const float*)tok_emb, pos_emb, feed, feed_ld, pos_p);
+        else hipLaunchKernelGGL((k_dec_ln<float, false>), grid, dim3(256), 0, s, x, lw, lb, (float*)y, rows, d, mpad, (const float*)nullptr, pos_emb, feed, feed_ld, pos_p);
+    } else {
+        if (tok_emb) hipLaunchKernelGGL((k_dec_ln<bf16, true>), grid, dim3(256), 0, s, x, lw, lb, (bf16*)y, rows, d, mpad, (const bf16*)tok_emb, pos_emb, feed, feed_ld, pos_p);
+        else hipLaunchKernelGGL((k_dec_ln<bf16, false>), grid, dim3(256), 0, s, x, lw, lb, (bf16*)y, rows, d, mpad, (const bf16*)nullptr, pos_emb, feed, feed_ld, pos_p);
     }
-    if (prec == WH_PREC_F32) { WH_PRO(float, float) }
-    else if (out_f32) { WH_PRO(bf16, float) }
-    else { WH_PRO(bf16, bf16) }
-#undef WH_PRO
 }
 
 template <typename T>
 void launch_lm_head_t(hipStream_t s, const SkinnyArgs& a) {
     const int n_tiles = (a.N + 15) / 16;
     int mt = std::min(4, (a.M + 15) / 16);
-    auto lds = [&](int t) { return (size_t)t * 16 * (a.K + 8) * sizeof(T); };
+    auto lds = [&](int t) { return (size_t)t * 16 * a.K * sizeof(T); };
     while (mt > 1 && lds(mt) > 150 * 1024) mt--;
     const size_t sm = lds(mt);
     const int per_cu = std::max<int>(1, (int)(150 * 1024 / sm));
-    dim3 grid(std::min((n_tiles + 3) / 4, 256 * std::min(per_cu, 2)), (a.M + 16 * mt - 1) / (16 * mt));
+    dim3 grid(std::min((n_tiles + 3) / 4, 256 * std::min(per_cu, wh_dbg_lm_blocks_per_cu)), (a.M + 16 * mt - 1) / (16 * mt));
 #define WH_LM(MT_)                                                \
     {                                                             \
         auto kfn = k_lm_head<T, MT_>;                             \
@@ -780,29 +713,29 @@ void wh_launch_argmax_finish(hipStream_t s, const float* part_val, const int* pa
 }
 
 void wh_launch_dec_self_attn(hipStream_t s, int prec, const void* qkv, void* kc, void* vc, void* out, const int* pos_p,
-                             int d, int n_heads, int tc, int B) {
+                             int d, int n_heads, int tc, int B, int mpad) {
     dim3 grid(n_heads, B);
     if (prec == WH_PREC_F32)
-        hipLaunchKernelGGL(k_dec_self_attn<float>, grid, dim3(64), 0, s, (const float*)qkv, (float*)kc, (float*)vc, (float*)out, pos_p, d, n_heads, tc);
+        hipLaunchKernelGGL(k_dec_self_attn<float>, grid, dim3(64), 0, s, (const float*)qkv, (float*)kc, (float*)vc, (float*)out, pos_p, d, n_heads, tc, mpad);
     else
-        hipLaunchKernelGGL(k_dec_self_attn<bf16>, grid, dim3(64), 0, s, (const bf16*)qkv, (bf16*)kc, (bf16*)vc, (bf16*)out, pos_p, d, n_heads, tc);
+        hipLaunchKernelGGL(k_dec_self_attn<bf16>, grid, dim3(64), 0, s, (const bf16*)qkv, (bf16*)kc, (bf16*)vc, (bf16*)out, pos_p, d, n_heads, tc, mpad);
 }
 
 void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void* ck, const void* cv, float* part,
-                              float* ml, void* out, int* tickets, int S, int d, int n_heads, int splits, int B) {
+                              float* ml, void* out, int* tickets, int S, int d, int n_heads, int splits, int B, int mpad) {
     dim3 grid(splits, B);
     const size_t sm = sizeof(float) * ((size_t)8 * n_heads + 4 * (size_t)d);
-#define WH_CA(T_, N_) hipLaunchKernelGGL((k_dec_cross_attn<T_, N_>), grid, dim3(256), sm, s, (const T_*)q, (const T_*)ck, \
-                                         (const T_*)cv, part, ml, (T_*)out, tickets, S, d, n_heads, splits)
+#define WH_CA(T_, N_, U_) hipLaunchKernelGGL((k_dec_cross_attn<T_, N_, U_>), grid, dim3(256), sm, s, (const T_*)q, (const T_*)ck, \
+                                             (const T_*)cv, part, ml, (T_*)out, tickets, S, d, n_heads, splits, mpad)
     if (prec == WH_PREC_F32) {
         const int nch = (d / 4 + 63) / 64;  // f32: 4 elements per chunk
-        if (nch == 1) WH_CA(float, 1);
-        else if (nch == 2) WH_CA(float, 2);
-        else WH_CA(float, 5);
+        if (nch == 1) WH_CA(float, 1, 4);
+        else if (nch == 2) WH_CA(float, 2, 2);
+        else WH_CA(float, 5, 1);
     } else {
         const int nch = (d / 8 + 63) / 64;
-        if (nch == 1) WH_CA(bf16, 1);
-        else WH_CA(bf16, 3);
+        if (nch == 1) { if (wh_dbg_cross_unroll == 8) WH_CA(bf16, 1, 8); else WH_CA(bf16, 1, 4); }
+        else WH_CA(bf16, 3, 2);
     }
 #undef WH_CA
 }

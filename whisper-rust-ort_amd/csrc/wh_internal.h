@@ -107,6 +107,7 @@ struct wh_ctx {
     float* logits = nullptr;    // optional parity buffer (grown on demand)
     size_t logits_cap = 0;
     int tok_ld = 0;
+    int mpad = 16;              // row pitch of the k-slab-major decode activations (multiple of 16)
     int cross_splits = 1;
 };
 

@@ -24,27 +24,20 @@ struct GemmArgs {
 };
 
 struct SkinnyArgs {
-    const void* X = nullptr;   // [M][ldx]
-    long ldx = 0;
+    const void* X = nullptr;   // activations, k-slab-major [K/32][x_mpad][32] (compute dtype)
+    int x_mpad = 64;
     const void* W = nullptr;   // [N][K]
     const float* bias = nullptr;
     const float* R = nullptr;  // residual f32 [M][ldr]
     long ldr = 0;
-    void* C = nullptr;
+    void* C = nullptr;         // output: row-major [M][ldc] (c_mpad == 0) or slab [N/32][c_mpad][32]
     long ldc = 0;
+    int c_mpad = 0;
     int M = 0, N = 0, K = 0, act = 0;
-    // fused prologues: LayerNorm of xres (pro 1) or embedding + LayerNorm (pro 2)
-    const float* xres = nullptr;     // [M][K] f32 residual stream
-    float* xres_out = nullptr;       // pro 2: where the embedded rows are written
-    const float *ln_w = nullptr, *ln_b = nullptr;
-    const void* tok_emb = nullptr;   // [V][K] compute dtype
-    const float* pos_emb = nullptr;  // [n_text_ctx][K]
-    const int* feed = nullptr;
-    int feed_ld = 0;
     // position advance by the last workgroup of the last kernel of a step
     int* ticket = nullptr;
     int* pos_w = nullptr;
-    // LM-head mode (pos_p is also read by the embedding prologue)
+    // LM-head mode
     const int* pos_p = nullptr;
     int n_prompt = 0;
     const unsigned* mask_first = nullptr;
@@ -84,11 +77,16 @@ void wh_launch_layernorm(hipStream_t s, int prec, const float* x, const float* w
 void wh_launch_enc_attn(hipStream_t s, int prec, const void* qk, const void* vT, void* out, int n_clips, int S, int d,
                         int n_heads, int ldv);
 
-void wh_launch_dec_gemm(hipStream_t s, int prec, bool out_f32, int pro, const SkinnyArgs& a);
+void wh_launch_dec_gemm(hipStream_t s, int prec, bool out_f32, const SkinnyArgs& a);
+void wh_launch_dec_ln(hipStream_t s, int prec, float* x, const float* lw, const float* lb, void* y, int rows, int d, int mpad,
+                      const void* tok_emb, const float* pos_emb, const int* feed, int feed_ld, const int* pos_p);
 void wh_launch_lm_head(hipStream_t s, int prec, const SkinnyArgs& a);
 void wh_launch_argmax_finish(hipStream_t s, const float* part_val, const int* part_idx, int n_tiles, int* pos_p,
                              int* ticket, const DecodeState& st, int B);
 void wh_launch_dec_self_attn(hipStream_t s, int prec, const void* qkv, void* kc, void* vc, void* out, const int* pos_p,
-                             int d, int n_heads, int tc, int B);
+                             int d, int n_heads, int tc, int B, int mpad);
 void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void* ck, const void* cv, float* part,
-                              float* ml, void* out, int* tickets, int S, int d, int n_heads, int splits, int B);
+                              float* ml, void* out, int* tickets, int S, int d, int n_heads, int splits, int B, int mpad);
+
+extern int wh_dbg_cross_unroll;
+extern int wh_dbg_lm_blocks_per_cu;
