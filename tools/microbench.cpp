@@ -41,7 +41,13 @@ int main(int argc, char** argv) {
         double us = time_chain(s, 200, [&]() { wh_launch_dec_gemm(s, prec, res, a); });
         printf("dec_gemm M=%d N=%4d K=%4d : %.2f us\n", B, nk.first, nk.second, us);
     }
-    printf("dec_ln rows=%d : %.2f us\n", B, time_chain(s, 200, [&]() { wh_launch_dec_ln(s, prec, xres, lnw, lnb, X, B, d, 64, nullptr, nullptr, nullptr, 0, nullptr); }));
+    {   // LN-folded consumer + stats-producing residual GEMM
+        float* part = (float*)dmalloc(32 * 64 * 2 * 4); float* sv = (float*)dmalloc(F * 4);
+        SkinnyArgs a; a.W = W; a.bias = bias; a.M = B; a.N = 3 * d; a.K = d; a.X = X; a.x_mpad = 64; a.C = C1; a.ldc = 3 * d; a.ln_part = part; a.ln_tiles = 32; a.ln_s = sv;
+        printf("dec_gemm LN-folded consumer N=1536 : %.2f us\n", time_chain(s, 200, [&]() { wh_launch_dec_gemm(s, prec, false, a); }));
+        SkinnyArgs p; p.W = W; p.bias = bias; p.M = B; p.N = d; p.K = d; p.X = X; p.x_mpad = 64; p.R = xres; p.ldr = d; p.C = xres; p.ldc = d; p.xslab_out = C1; p.stats_out = part;
+        printf("dec_gemm stats producer N=512 : %.2f us\n", time_chain(s, 200, [&]() { wh_launch_dec_gemm(s, prec, true, p); }));
+    }
     {   // LM head
         SkinnyArgs a; a.W = W; a.X = X; a.x_mpad = 64; a.M = B; a.N = V; a.K = d; a.pos_p = pos; a.n_prompt = 1;
         a.mask_first = (unsigned*)dmalloc(V / 8 + 64); a.mask_base = a.mask_first; a.part_val = (float*)dmalloc((size_t)64 * 4096 * 4); a.part_idx = (int*)dmalloc((size_t)64 * 4096 * 4);

@@ -272,20 +272,25 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     std::vector<int> done_h(nb);
     // one decoder position = ~50 kernel launches; `emits` adds final LN + LM head + argmax
     const int mpad = c->mpad;  // row pitch of the k-slab-major decode activations
+    // LayerNorm never runs as a kernel in the decoder: the kernel that produces a residual-stream row also
+    // emits its raw copy in the compute dtype (c->dxs, slab layout) and per-column-tile partial sums
+    // (c->lnpart); the GEMM that consumes LN(x) has γ folded into its weights and applies mean / rstd in
+    // its epilogue (wh_model.cpp fold_ln).
+    const int ln_tiles_d = (int)(d / 16);
     auto launch_step = [&](bool emits) {
+        {   // token + position embedding → x, raw slab, row sums (one "tile")
+            Prof pr(c, WH_KG_DEC_OTHER);
+            wh_launch_dec_embed(s, prec, m->tok_emb, m->dec_pos, c->feed, ld, c->pos, c->dx, c->dxs, c->lnpart, nb, (int)d, mpad);
+        }
         for (int l = 0; l < D.dec_layers; l++) {
             const DecLayerDev& L = m->dec[l];
             SkinnyArgs a;
-            {   // [token + position embedding →] LN1 (slab) → Q|K|V projection
-                Prof pr(c, WH_KG_DEC_OTHER);
-                wh_launch_dec_ln(s, prec, c->dx, L.ln1_w, L.ln1_b, c->dxn, nb, (int)d, mpad, l == 0 ? m->tok_emb : nullptr, m->dec_pos,
-                                 c->feed, ld, c->pos);
-            }
-            {
+            {   // LN1 ∘ Q|K|V projection
                 Prof pr(c, WH_KG_DEC_GEMM);
                 a = SkinnyArgs();
-                a.X = c->dxn; a.x_mpad = mpad; a.W = L.qkv_w; a.bias = L.qkv_b; a.C = c->dqkv; a.ldc = 3 * d;
+                a.X = c->dxs; a.x_mpad = mpad; a.W = L.qkv_w; a.bias = L.qkv_b; a.C = c->dqkv; a.ldc = 3 * d;
                 a.M = nb; a.N = (int)(3 * d); a.K = (int)d;
+                a.ln_part = c->lnpart; a.ln_tiles = (l == 0) ? 1 : ln_tiles_d; a.ln_s = L.qkv_s;
                 wh_launch_dec_gemm(s, prec, false, a);
             }
             {
@@ -294,18 +299,18 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                                         (char*)c->self_v + l * cache_l * esz, c->datt, c->pos, (int)d, D.n_heads,
                                         D.n_text_ctx, nb, mpad);
             }
-            {   // self-attention out-proj + residual
+            {   // self-attention out-proj + residual → x, raw slab, LN2 partials
                 Prof pr(c, WH_KG_DEC_GEMM);
                 a = SkinnyArgs();
                 a.X = c->datt; a.x_mpad = mpad; a.W = L.o_w; a.bias = L.o_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
-                a.M = nb; a.N = (int)d; a.K = (int)d;
+                a.M = nb; a.N = (int)d; a.K = (int)d; a.xslab_out = c->dxs; a.stats_out = c->lnpart;
                 wh_launch_dec_gemm(s, prec, true, a);
             }
-            { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_dec_ln(s, prec, c->dx, L.ln2_w, L.ln2_b, c->dxn, nb, (int)d, mpad, nullptr, nullptr, nullptr, 0, nullptr); }
-            {   // cross-attention query
+            {   // LN2 ∘ cross-attention query
                 Prof pr(c, WH_KG_DEC_GEMM);
                 a = SkinnyArgs();
-                a.X = c->dxn; a.x_mpad = mpad; a.W = L.cq_w; a.bias = L.cq_b; a.C = c->dq; a.ldc = d; a.M = nb; a.N = (int)d; a.K = (int)d;
+                a.X = c->dxs; a.x_mpad = mpad; a.W = L.cq_w; a.bias = L.cq_b; a.C = c->dq; a.ldc = d; a.M = nb; a.N = (int)d; a.K = (int)d;
+                a.ln_part = c->lnpart; a.ln_tiles = ln_tiles_d; a.ln_s = L.cq_s;
                 wh_launch_dec_gemm(s, prec, false, a);
             }
             {
@@ -314,37 +319,37 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                                          (char*)c->cross_kv + (2 * l + 1) * kv_stride * esz, c->cpart, c->cml, c->datt,
                                          c->cross_tickets, (int)S, (int)d, D.n_heads, c->cross_splits, nb, mpad);
             }
-            {   // cross-attention out-proj + residual
+            {   // cross-attention out-proj + residual → x, raw slab, LN3 partials
                 Prof pr(c, WH_KG_DEC_GEMM);
                 a = SkinnyArgs();
                 a.X = c->datt; a.x_mpad = mpad; a.W = L.co_w; a.bias = L.co_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
-                a.M = nb; a.N = (int)d; a.K = (int)d;
+                a.M = nb; a.N = (int)d; a.K = (int)d; a.xslab_out = c->dxs; a.stats_out = c->lnpart;
                 wh_launch_dec_gemm(s, prec, true, a);
             }
-            { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_dec_ln(s, prec, c->dx, L.ln3_w, L.ln3_b, c->dxn, nb, (int)d, mpad, nullptr, nullptr, nullptr, 0, nullptr); }
-            {   // fc1 + GELU (slab output), fc2 + residual
+            {   // LN3 ∘ fc1 + GELU (slab output)
                 Prof pr(c, WH_KG_DEC_GEMM);
                 a = SkinnyArgs();
-                a.X = c->dxn; a.x_mpad = mpad; a.W = L.fc1_w; a.bias = L.fc1_b; a.act = 1; a.C = c->dh; a.c_mpad = mpad;
+                a.X = c->dxs; a.x_mpad = mpad; a.W = L.fc1_w; a.bias = L.fc1_b; a.act = 1; a.C = c->dh; a.c_mpad = mpad;
                 a.M = nb; a.N = (int)F; a.K = (int)d;
+                a.ln_part = c->lnpart; a.ln_tiles = ln_tiles_d; a.ln_s = L.fc1_s;
                 wh_launch_dec_gemm(s, prec, false, a);
             }
-            {
+            {   // fc2 + residual → x, raw slab, partials for the next layer's LN1 / the final LN
                 Prof pr(c, WH_KG_DEC_GEMM);
                 a = SkinnyArgs();
                 a.X = c->dh; a.x_mpad = mpad; a.W = L.fc2_w; a.bias = L.fc2_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
-                a.M = nb; a.N = (int)d; a.K = (int)F;
+                a.M = nb; a.N = (int)d; a.K = (int)F; a.xslab_out = c->dxs; a.stats_out = c->lnpart;
                 if (!emits && l == D.dec_layers - 1) { a.ticket = c->step_ticket; a.pos_w = c->pos; }  // prompt position: advance here
                 wh_launch_dec_gemm(s, prec, true, a);
             }
         }
-        if (emits) {  // final LN + tied LM head + masked argmax; the finish kernel advances the position
-            { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_dec_ln(s, prec, c->dx, m->dec_ln_w, m->dec_ln_b, c->dxn, nb, (int)d, mpad, nullptr, nullptr, nullptr, 0, nullptr); }
+        if (emits) {  // final LN ∘ tied LM head + masked argmax; the finish kernel advances the position
             {
                 Prof pr(c, WH_KG_DEC_GEMM);
                 SkinnyArgs a;
-                a.W = m->tok_emb; a.M = nb; a.N = D.vocab; a.K = (int)d;
-                a.X = c->dxn; a.x_mpad = mpad;
+                a.W = m->lm_w; a.bias = m->lm_c; a.ln_s = m->lm_s; a.ln_part = c->lnpart; a.ln_tiles = ln_tiles_d;
+                a.M = nb; a.N = D.vocab; a.K = (int)d;
+                a.X = c->dxs; a.x_mpad = mpad;
                 a.pos_p = c->pos; a.n_prompt = P; a.mask_first = c->mask_first; a.mask_base = c->mask_base;
                 a.logits = d_logits; a.logits_rows = (int)logits_rows; a.part_val = c->part_val; a.part_idx = c->part_idx;
                 wh_launch_lm_head(s, prec, a);
@@ -574,6 +579,7 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
     const size_t o_sk = cv.take(Ld * B * H * TC * WH_HEAD_DIM * esz), o_sv = cv.take(Ld * B * H * TC * WH_HEAD_DIM * esz);
     const size_t MP = align_up(B, 16);  // slab-layout activations: [K/32][MP][32]
     const size_t o_dx = cv.take(B * d * 4), o_dxn = cv.take(MP * d * esz), o_dqkv = cv.take(B * 3 * d * esz);
+    const size_t o_dxs = cv.take(MP * d * esz), o_lnp = cv.take((d / 16) * MP * 2 * 4);
     const size_t o_datt = cv.take(MP * d * esz), o_dq = cv.take(B * d * esz), o_dh = cv.take(MP * F * esz);
     const size_t o_cpart = cv.take(B * c->cross_splits * d * 4), o_cml = cv.take(B * c->cross_splits * H * 2 * 4);
     const size_t o_pv = cv.take(B * n_tiles * 4), o_pi = cv.take(B * n_tiles * 4);
@@ -592,7 +598,7 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
     c->melT = w + o_melT; c->h1 = w + o_h1; c->x = (float*)(w + o_x); c->xn = w + o_xn; c->qk = w + o_qk;
     c->vT = w + o_vT; c->att = w + o_att; c->hbuf = w + o_h; c->enc_out = w + o_enc; c->enc_out_f32 = (float*)(w + o_encf);
     c->cross_kv = w + o_ckv; c->self_k = w + o_sk; c->self_v = w + o_sv;
-    c->dx = (float*)(w + o_dx); c->dxn = w + o_dxn; c->dqkv = w + o_dqkv; c->datt = w + o_datt; c->dq = w + o_dq; c->dh = w + o_dh;
+    c->dx = (float*)(w + o_dx); c->dxn = w + o_dxn; c->dxs = w + o_dxs; c->lnpart = (float*)(w + o_lnp); c->dqkv = w + o_dqkv; c->datt = w + o_datt; c->dq = w + o_dq; c->dh = w + o_dh;
     c->cpart = (float*)(w + o_cpart); c->cml = (float*)(w + o_cml); c->part_val = (float*)(w + o_pv); c->part_idx = (int*)(w + o_pi);
     c->feed = (int*)(w + o_feed); c->out_tokens = (int*)(w + o_out); c->n_out = (int*)(w + o_nout); c->done = (int*)(w + o_done);
     c->forced = (int*)(w + o_forced); c->pos = (int*)(w + o_pos);

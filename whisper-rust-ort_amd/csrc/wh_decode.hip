@@ -56,62 +56,32 @@ __device__ __forceinline__ void advance_if_last(int* ticket, int* pos_p, int n_b
 // [M][K] buffer.  Producers (LayerNorm, attention, fc1 epilogue) write this layout directly.
 __device__ __forceinline__ long slab_idx(int m, int k, int mpad) { return ((long)(k >> 5) * mpad + m) * 32 + (k & 31); }
 
-// LayerNorm of decode rows (f32 residual stream → compute dtype, slab layout); optionally the rows
-// are first formed as token embedding + learned position ([3P] :737, :757-766) and written to x.
-// One wave per row.  [3P] torch LayerNorm eps 1e-5, biased variance (modeling_whisper.py:371).
-template <typename T, bool EMBED>
-__global__ __launch_bounds__(256) void k_dec_ln(float* __restrict__ x, const float* __restrict__ lw,
-                                                const float* __restrict__ lb, T* __restrict__ y, int rows, int d,
-                                                int mpad, const T* __restrict__ tok_emb,
-                                                const float* __restrict__ pos_emb, const int* __restrict__ feed,
-                                                int feed_ld, const int* __restrict__ pos_p) {
+// Token embedding + learned position ([3P] :737, :757-766) for the rows of this position: writes the f32
+// residual stream, its raw copy in the compute dtype (slab layout) and each row's {sum x, sum x^2}
+// (one "tile" of LayerNorm partials).  One wave per row.
+template <typename T>
+__global__ __launch_bounds__(256) void k_dec_embed(const T* __restrict__ tok_emb, const float* __restrict__ pos_emb,
+                                                   const int* __restrict__ feed, int feed_ld,
+                                                   const int* __restrict__ pos_p, float* __restrict__ x,
+                                                   T* __restrict__ xslab, float* __restrict__ stats, int rows, int d,
+                                                   int mpad) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const int lane = threadIdx.x & 63;
-    constexpr int NV = 5;  // d <= 1280
-    f32x4 v[NV], ww[NV], bb[NV];
-    float* xr = x + (long)row * d;
-    const T* er = nullptr;
-    const float* pr = nullptr;
-    if (EMBED) {
-        const int pos = *pos_p;
-        er = tok_emb + (long)feed[row * feed_ld + pos] * d;
-        pr = pos_emb + (long)pos * d;
+    const int lane = threadIdx.x & 63, pos = *pos_p;
+    const T* er = tok_emb + (long)feed[row * feed_ld + pos] * d;
+    const float* pr = pos_emb + (long)pos * d;
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int c = lane * 4; c < d; c += 256) {
+        f32x4 p = *reinterpret_cast<const f32x4*>(pr + c);
+        f32x4 v = {cvt_in<T>(er[c]) + p[0], cvt_in<T>(er[c + 1]) + p[1], cvt_in<T>(er[c + 2]) + p[2], cvt_in<T>(er[c + 3]) + p[3]};
+        *reinterpret_cast<f32x4*>(x + (long)row * d + c) = v;
+        store4(xslab + slab_idx(row, c, mpad), v[0], v[1], v[2], v[3]);
+        s1 += (v[0] + v[1]) + (v[2] + v[3]);
+        s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
-    float s = 0.0f;
-#pragma unroll
-    for (int i = 0; i < NV; i++) {
-        const int c = (i * 64 + lane) * 4;
-        v[i] = f32x4{0, 0, 0, 0};
-        if (c < d) {
-            ww[i] = *reinterpret_cast<const f32x4*>(lw + c);
-            bb[i] = *reinterpret_cast<const f32x4*>(lb + c);
-            if (EMBED) {
-                f32x4 p = *reinterpret_cast<const f32x4*>(pr + c);
-                v[i] = f32x4{cvt_in<T>(er[c]) + p[0], cvt_in<T>(er[c + 1]) + p[1], cvt_in<T>(er[c + 2]) + p[2], cvt_in<T>(er[c + 3]) + p[3]};
-                *reinterpret_cast<f32x4*>(xr + c) = v[i];
-            } else {
-                v[i] = *reinterpret_cast<const f32x4*>(xr + c);
-            }
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        }
-    }
-    const float mean = wave_sum(s) / (float)d;
-    float q = 0.0f;
-#pragma unroll
-    for (int i = 0; i < NV; i++)
-        if ((i * 64 + lane) * 4 < d) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) { float t = v[i][e] - mean; q += t * t; }
-        }
-    const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
-#pragma unroll
-    for (int i = 0; i < NV; i++) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < d)
-            store4(y + slab_idx(row, c, mpad), (v[i][0] - mean) * rstd * ww[i][0] + bb[i][0], (v[i][1] - mean) * rstd * ww[i][1] + bb[i][1],
-                   (v[i][2] - mean) * rstd * ww[i][2] + bb[i][2], (v[i][3] - mean) * rstd * ww[i][3] + bb[i][3]);
-    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) { stats[2 * row] = s1; stats[2 * row + 1] = s2; }
 }
 
 // ---- decode GEMM: C[m][n] = act(sum_k X[m][k] W[n][k] + bias[n]) (+ R[m][n]),  M <= 64 per row group
@@ -149,6 +119,34 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
         if (a.bias) pre_bias = *reinterpret_cast<const f32x4*>(a.bias + en);
         if (a.R) pre_r = *reinterpret_cast<const f32x4*>(a.R + (long)em * a.ldr + en);
     }
+    // LayerNorm folded in: reduce the producer's per-tile partial sums of this row group to mean / rstd
+    // (while the weight and activation fragments above are in flight)
+    float* lnred = reinterpret_cast<float*>(smem_raw) + (size_t)NW * MT * 64 * 4;  // [4][MT*16][2], then stat[MT*16][2]
+    float ln_mean = 0.0f, ln_rstd = 1.0f, ln_sv[4] = {0, 0, 0, 0};
+    if (a.ln_part) {
+        constexpr int ROWS = MT * 16;
+        if (tid < 4 * ROWS) {
+            const int r = tid % ROWS, q = tid / ROWS;
+            float s1 = 0.0f, s2 = 0.0f;
+            for (int tl = q; tl < a.ln_tiles; tl += 4) {
+                const float* pp = a.ln_part + ((long)tl * a.x_mpad + m0 + r) * 2;
+                s1 += pp[0];
+                s2 += pp[1];
+            }
+            lnred[(q * ROWS + r) * 2] = s1;
+            lnred[(q * ROWS + r) * 2 + 1] = s2;
+        }
+        __syncthreads();
+        if (ep_ok) {
+            const int r = wave * 16 + fl;
+            const float s1 = (lnred[r * 2] + lnred[(ROWS + r) * 2]) + (lnred[(2 * ROWS + r) * 2] + lnred[(3 * ROWS + r) * 2]);
+            const float s2 = (lnred[r * 2 + 1] + lnred[(ROWS + r) * 2 + 1]) + (lnred[(2 * ROWS + r) * 2 + 1] + lnred[(3 * ROWS + r) * 2 + 1]);
+            ln_mean = s1 / (float)a.K;
+            ln_rstd = rsqrtf(fmaxf(s2 / (float)a.K - ln_mean * ln_mean, 0.0f) + 1e-5f);  // biased variance, eps 1e-5
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(a.ln_s + en);
+            ln_sv[0] = sv[0]; ln_sv[1] = sv[1]; ln_sv[2] = sv[2]; ln_sv[3] = sv[3];
+        }
+    }
     f32x4 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; t++) acc[t] = f32x4{0, 0, 0, 0};
@@ -183,12 +181,37 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            v[e] = s[e] + pre_bias[e];
+            v[e] = a.ln_part ? ln_rstd * (s[e] - ln_mean * ln_sv[e]) + pre_bias[e] : s[e] + pre_bias[e];
             if (a.act == 1) v[e] = gelu_erf(v[e]);
             v[e] += pre_r[e];
         }
         TO* dst = a.c_mpad ? (TO*)a.C + slab_idx(em, en, a.c_mpad) : (TO*)a.C + (long)em * a.ldc + en;
         store4(dst, v[0], v[1], v[2], v[3]);
+        if (a.xslab_out) store4((T*)a.xslab_out + slab_idx(em, en, a.x_mpad), v[0], v[1], v[2], v[3]);
+    }
+    if (a.stats_out && wave < MT) {
+        // this column tile's {sum x, sum x^2} per row: 4 values per lane, then the 4 lane groups of the row
+        float s1 = 0.0f, s2 = 0.0f;
+        if (ep_ok) {
+            f32x4 s = red[(0 * MT + wave) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < NW; w++) {
+                f32x4 o = red[(w * MT + wave) * 64 + lane];
+                s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float v = s[e] + pre_bias[e] + pre_r[e];  // producers have no activation
+                s1 += v;
+                s2 += v * v;
+            }
+        }
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        if (fg == 0 && em < a.M) {
+            a.stats_out[((long)blockIdx.x * a.x_mpad + em) * 2] = s1;
+            a.stats_out[((long)blockIdx.x * a.x_mpad + em) * 2 + 1] = s2;
+        }
     }
     advance_if_last(a.ticket, a.pos_w, gridDim.x * gridDim.y);
 }
@@ -214,6 +237,19 @@ __global__ __launch_bounds__(256) void k_lm_head(SkinnyArgs a) {
         const int sl = c / cps, o = (c - sl * cps) * EPC;
         *reinterpret_cast<u32x4*>(Xs + (long)sl * ROWS * 32 + o) =
             *reinterpret_cast<const u32x4*>((const T*)a.X + ((long)sl * a.x_mpad + m0) * 32 + o);
+    }
+    // final LayerNorm folded in: mean / rstd of this row group from the producer's per-tile partial sums
+    float* lnstat = reinterpret_cast<float*>(smem_raw + (size_t)nslab * ROWS * 32 * sizeof(T));  // [ROWS][2]
+    if (a.ln_part && tid < ROWS) {
+        float s1 = 0.0f, s2 = 0.0f;
+        for (int tl = 0; tl < a.ln_tiles; tl++) {
+            const float* pp = a.ln_part + ((long)tl * a.x_mpad + m0 + tid) * 2;
+            s1 += pp[0];
+            s2 += pp[1];
+        }
+        const float mean = s1 / (float)a.K;
+        lnstat[2 * tid] = mean;
+        lnstat[2 * tid + 1] = rsqrtf(fmaxf(s2 / (float)a.K - mean * mean, 0.0f) + 1e-5f);
     }
     const int pos = *a.pos_p;
     const int gen = pos - (a.n_prompt - 1);  // index of the token this row generates
@@ -256,15 +292,22 @@ __global__ __launch_bounds__(256) void k_lm_head(SkinnyArgs a) {
         }
         if (ck != nchunk - 1) return;
         const int n = tile * 16 + 4 * fg;
+        float sv[4] = {0, 0, 0, 0}, cv[4] = {0, 0, 0, 0};
+        if (a.ln_part) {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (n + e < a.N) { sv[e] = a.ln_s[n + e]; cv[e] = a.bias[n + e]; }
+        }
 #pragma unroll
         for (int t = 0; t < MT; t++) {
             const int m = m0 + t * 16 + fl;
+            const float mean = a.ln_part ? lnstat[2 * (t * 16 + fl)] : 0.0f, rstd = a.ln_part ? lnstat[2 * (t * 16 + fl) + 1] : 1.0f;
             float bv = -INFINITY;
             int bi = 0x7fffffff;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int nn = n + e;
-                const float v = acc[t][e];
+                const float v = a.ln_part ? rstd * (acc[t][e] - mean * sv[e]) + cv[e] : acc[t][e];
                 if (nn < a.N && m < a.M) {
                     if (a.logits && gen >= 0 && gen < a.logits_rows)
                         a.logits[((long)m * a.logits_rows + gen) * a.N + nn] = v;
@@ -637,7 +680,7 @@ template <typename T, typename TO, int NW>
 void launch_dec_gemm_mt(hipStream_t s, const SkinnyArgs& a) {
     const int n_tiles = (a.N + 15) / 16;
     const int mt = std::min(4, (a.M + 15) / 16);
-    const size_t sm = (size_t)NW * mt * 64 * 16;
+    const size_t sm = (size_t)NW * mt * 64 * 16 + (size_t)4 * mt * 16 * 2 * 4;
     dim3 grid(n_tiles, (a.M + 16 * mt - 1) / (16 * mt));
     switch (mt) {
         case 1: hipLaunchKernelGGL((k_dec_gemm<T, TO, 1, NW>), grid, dim3(NW * 64), sm, s, a); break;
@@ -663,25 +706,20 @@ void wh_launch_dec_gemm(hipStream_t s, int prec, bool out_f32, const SkinnyArgs&
     else launch_dec_gemm_split<bf16, bf16>(s, a);
 }
 
-// x (f32 rows) → LayerNorm → y (compute dtype, slab layout).  tok_emb != nullptr: the rows are first
-// formed as token embedding + position and written to x.
-void wh_launch_dec_ln(hipStream_t s, int prec, float* x, const float* lw, const float* lb, void* y, int rows, int d, int mpad,
-                      const void* tok_emb, const float* pos_emb, const int* feed, int feed_ld, const int* pos_p) {
+void wh_launch_dec_embed(hipStream_t s, int prec, const void* tok_emb, const float* pos_emb, const int* feed, int feed_ld,
+                         const int* pos_p, float* x, void* xslab, float* stats, int rows, int d, int mpad) {
     dim3 grid((rows + 3) / 4);
-    if (prec == WH_PREC_F32) {
-        if (tok_emb) hipLaunchKernelGGL((k_dec_ln<float, true>), grid, dim3(256), 0, s, x, lw, lb, (float*)y, rows, d, mpad, (const float*)tok_emb, pos_emb, feed, feed_ld, pos_p);
-        else hipLaunchKernelGGL((k_dec_ln<float, false>), grid, dim3(256), 0, s, x, lw, lb, (float*)y, rows, d, mpad, (const float*)nullptr, pos_emb, feed, feed_ld, pos_p);
-    } else {
-        if (tok_emb) hipLaunchKernelGGL((k_dec_ln<bf16, true>), grid, dim3(256), 0, s, x, lw, lb, (bf16*)y, rows, d, mpad, (const bf16*)tok_emb, pos_emb, feed, feed_ld, pos_p);
-        else hipLaunchKernelGGL((k_dec_ln<bf16, false>), grid, dim3(256), 0, s, x, lw, lb, (bf16*)y, rows, d, mpad, (const bf16*)nullptr, pos_emb, feed, feed_ld, pos_p);
-    }
+    if (prec == WH_PREC_F32)
+        hipLaunchKernelGGL(k_dec_embed<float>, grid, dim3(256), 0, s, (const float*)tok_emb, pos_emb, feed, feed_ld, pos_p, x, (float*)xslab, stats, rows, d, mpad);
+    else
+        hipLaunchKernelGGL(k_dec_embed<bf16>, grid, dim3(256), 0, s, (const bf16*)tok_emb, pos_emb, feed, feed_ld, pos_p, x, (bf16*)xslab, stats, rows, d, mpad);
 }
 
 template <typename T>
 void launch_lm_head_t(hipStream_t s, const SkinnyArgs& a) {
     const int n_tiles = (a.N + 15) / 16;
     int mt = std::min(4, (a.M + 15) / 16);
-    auto lds = [&](int t) { return (size_t)t * 16 * a.K * sizeof(T); };
+    auto lds = [&](int t) { return (size_t)t * 16 * a.K * sizeof(T) + (size_t)t * 16 * 2 * 4; };
     while (mt > 1 && lds(mt) > 150 * 1024) mt--;
     const size_t sm = lds(mt);
     const int per_cu = std::max<int>(1, (int)(150 * 1024 / sm));

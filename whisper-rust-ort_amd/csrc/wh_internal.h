@@ -18,6 +18,8 @@ struct DecLayerDev {
     void *qkv_w, *o_w, *cq_w, *co_w, *fc1_w, *fc2_w;
     float *qkv_b, *o_b, *cq_b, *co_b, *fc1_b, *fc2_b;
     float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *ln3_w, *ln3_b;
+    // LayerNorm folded into the consumer GEMMs: qkv_w/cq_w/fc1_w hold W ⊙ γ, *_b hold c[n], *_s hold s[n]
+    float *qkv_s, *cq_s, *fc1_s;
 };
 
 struct wh_model {
@@ -35,6 +37,8 @@ struct wh_model {
     void *conv1_w = nullptr, *conv2_w = nullptr, *tok_emb = nullptr, *cross_kv_w = nullptr;
     float *conv1_b = nullptr, *conv2_b = nullptr, *enc_pos = nullptr, *dec_pos = nullptr, *cross_kv_b = nullptr;
     float *enc_ln_w = nullptr, *enc_ln_b = nullptr, *dec_ln_w = nullptr, *dec_ln_b = nullptr;
+    void* lm_w = nullptr;  // tied embedding ⊙ final-LN γ (LM head operand)
+    float *lm_s = nullptr, *lm_c = nullptr;
     std::vector<EncLayerDev> enc;
     std::vector<DecLayerDev> dec;
     // log-mel tables
@@ -93,6 +97,8 @@ struct wh_ctx {
     // decode step buffers
     float* dx = nullptr;        // [B][d]
     void* dxn = nullptr;        // [B][d]
+    void* dxs = nullptr;        // raw residual rows, compute dtype, slab layout [d/32][mpad][32]
+    float* lnpart = nullptr;    // LayerNorm partial sums [d/16][mpad][2]
     void* dqkv = nullptr;       // [B][3d]
     void* datt = nullptr;       // [B][d]
     void* dq = nullptr;         // [B][d]

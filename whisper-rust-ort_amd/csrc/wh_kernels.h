@@ -34,6 +34,15 @@ struct SkinnyArgs {
     long ldc = 0;
     int c_mpad = 0;
     int M = 0, N = 0, K = 0, act = 0;
+    // LayerNorm folded into this GEMM (consumer): y = rstd[m] * (acc - mean[m] * ln_s[n]) + bias[n], with
+    // mean/rstd of row m reduced from ln_tiles per-tile partial sums {sum x, sum x^2} [ln_tiles][x_mpad][2]
+    const float* ln_part = nullptr;
+    int ln_tiles = 0;
+    const float* ln_s = nullptr;
+    // producer of the next LayerNorm's input: besides C (f32 row-major residual stream) also write the
+    // raw rows in the compute dtype, slab layout, and this column tile's partial sums
+    void* xslab_out = nullptr;   // [N/32][x_mpad][32]
+    float* stats_out = nullptr;  // [N/16][x_mpad][2]
     // position advance by the last workgroup of the last kernel of a step
     int* ticket = nullptr;
     int* pos_w = nullptr;
@@ -78,8 +87,8 @@ void wh_launch_enc_attn(hipStream_t s, int prec, const void* qk, const void* vT,
                         int n_heads, int ldv);
 
 void wh_launch_dec_gemm(hipStream_t s, int prec, bool out_f32, const SkinnyArgs& a);
-void wh_launch_dec_ln(hipStream_t s, int prec, float* x, const float* lw, const float* lb, void* y, int rows, int d, int mpad,
-                      const void* tok_emb, const float* pos_emb, const int* feed, int feed_ld, const int* pos_p);
+void wh_launch_dec_embed(hipStream_t s, int prec, const void* tok_emb, const float* pos_emb, const int* feed, int feed_ld,
+                         const int* pos_p, float* x, void* xslab, float* stats, int rows, int d, int mpad);
 void wh_launch_lm_head(hipStream_t s, int prec, const SkinnyArgs& a);
 void wh_launch_argmax_finish(hipStream_t s, const float* part_val, const int* part_idx, int n_tiles, int* pos_p,
                              int* ticket, const DecodeState& st, int B);

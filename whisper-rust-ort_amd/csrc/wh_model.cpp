@@ -320,6 +320,8 @@ static inline uint16_t f32_to_bf16(float f) {  // round-to-nearest-even, NaN kep
     return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
+static inline float bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
 namespace {
 struct Stager {
     std::vector<char> host;
@@ -442,7 +444,26 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     size_t o_elnw = st.put_f32(T(e + ".layer_norm.weight"), d), o_elnb = st.put_f32(T(e + ".layer_norm.bias"), d);
     size_t o_tok = st.put_mat(T(dd + ".embed_tokens.weight"), c.vocab, d, d);
     size_t o_dpos = st.put_f32(T(dd + ".embed_positions.weight"), (size_t)c.n_text_ctx * d);
-    struct DecOff { size_t qkv, qkvb, o, ob, cq, cqb, co, cob, f1, f1b, f2, f2b, l1w, l1b, l2w, l2b, l3w, l3b; };
+    struct DecOff { size_t qkv, qkvb, qkvs, o, ob, cq, cqb, cqs, co, cob, f1, f1b, f1s, f2, f2b, l1w, l1b, l2w, l2b, l3w, l3b; };
+    // LayerNorm folded into the consumer GEMM: rows [row0, row0+rows) of the matrix at `off`
+    // become W'[r][k] = rscale * W[r][k] * gamma[k] in the compute dtype; s[r] = sum_k W'[r][k] (of the values
+    // as stored), c[r] = sum_k beta[k] * rscale * W[r][k] + rscale * bias[r]
+    auto fold_ln = [&](size_t off, size_t row0, const float* W, size_t rows, size_t cols, float rscale, const float* gamma,
+                       const float* beta, const float* bias, float* s_out, float* c_out) {
+        std::vector<float> row(cols);
+        for (size_t r = 0; r < rows; r++) {
+            double sacc = 0.0, cacc = bias ? (double)bias[r] * rscale : 0.0;
+            for (size_t k = 0; k < cols; k++) {
+                const float w = W[r * cols + k] * rscale;
+                row[k] = w * gamma[k];
+                sacc += (m->esz == 2) ? (double)bf16_to_f32(f32_to_bf16(row[k])) : (double)row[k];
+                cacc += (double)beta[k] * (double)w;
+            }
+            st.put_row(off, row0 + r, cols, row.data(), cols, 1.0f);
+            s_out[r] = (float)sacc;
+            c_out[r] = (float)cacc;
+        }
+    };
     std::vector<DecOff> dof(c.dec_layers);
     const size_t Ld = c.dec_layers;
     size_t o_ckv = st.reserve(Ld * 2 * d * d * m->esz);
@@ -451,22 +472,22 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     for (int i = 0; i < c.dec_layers; i++) {
         std::string p = dd + ".layers." + std::to_string(i);
         DecOff& x = dof[i];
+        const float *g1 = T(p + ".self_attn_layer_norm.weight"), *b1 = T(p + ".self_attn_layer_norm.bias");
         x.qkv = st.reserve(3 * d * d * m->esz);
-        for (size_t r = 0; r < d; r++) {
-            st.put_row(x.qkv, r, d, T(p + ".self_attn.q_proj.weight") + r * d, d, qs);
-            st.put_row(x.qkv, d + r, d, T(p + ".self_attn.k_proj.weight") + r * d, d, 1.0f);
-            st.put_row(x.qkv, 2 * d + r, d, T(p + ".self_attn.v_proj.weight") + r * d, d, 1.0f);
-        }
-        std::vector<float> b3(3 * d, 0.0f);
-        for (size_t r = 0; r < d; r++) {
-            b3[r] = T(p + ".self_attn.q_proj.bias")[r] * qs;
-            b3[2 * d + r] = T(p + ".self_attn.v_proj.bias")[r];
-        }
-        x.qkvb = st.put_f32(b3.data(), 3 * d);
+        std::vector<float> s3(3 * d), c3(3 * d), s1(std::max(d, F)), c1(std::max(d, F));
+        fold_ln(x.qkv, 0, T(p + ".self_attn.q_proj.weight"), d, d, qs, g1, b1, T(p + ".self_attn.q_proj.bias"), s3.data(), c3.data());
+        fold_ln(x.qkv, d, T(p + ".self_attn.k_proj.weight"), d, d, 1.0f, g1, b1, nullptr, s3.data() + d, c3.data() + d);
+        fold_ln(x.qkv, 2 * d, T(p + ".self_attn.v_proj.weight"), d, d, 1.0f, g1, b1, T(p + ".self_attn.v_proj.bias"), s3.data() + 2 * d,
+                c3.data() + 2 * d);
+        x.qkvb = st.put_f32(c3.data(), 3 * d);
+        x.qkvs = st.put_f32(s3.data(), 3 * d);
         x.o = st.put_mat(T(p + ".self_attn.out_proj.weight"), d, d, d);
         x.ob = st.put_f32(T(p + ".self_attn.out_proj.bias"), d);
-        x.cq = st.put_mat(T(p + ".encoder_attn.q_proj.weight"), d, d, d, qs);
-        x.cqb = st.put_f32(T(p + ".encoder_attn.q_proj.bias"), d, qs);
+        x.cq = st.reserve(d * d * m->esz);
+        fold_ln(x.cq, 0, T(p + ".encoder_attn.q_proj.weight"), d, d, qs, T(p + ".encoder_attn_layer_norm.weight"),
+                T(p + ".encoder_attn_layer_norm.bias"), T(p + ".encoder_attn.q_proj.bias"), s1.data(), c1.data());
+        x.cqb = st.put_f32(c1.data(), d);
+        x.cqs = st.put_f32(s1.data(), d);
         x.co = st.put_mat(T(p + ".encoder_attn.out_proj.weight"), d, d, d);
         x.cob = st.put_f32(T(p + ".encoder_attn.out_proj.bias"), d);
         for (size_t r = 0; r < d; r++) {
@@ -474,8 +495,11 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
             st.put_row(o_ckv, ((size_t)i * 2 + 1) * d + r, d, T(p + ".encoder_attn.v_proj.weight") + r * d, d, 1.0f);
             ckvb[((size_t)i * 2 + 1) * d + r] = T(p + ".encoder_attn.v_proj.bias")[r];
         }
-        x.f1 = st.put_mat(T(p + ".fc1.weight"), F, d, d);
-        x.f1b = st.put_f32(T(p + ".fc1.bias"), F);
+        x.f1 = st.reserve(F * d * m->esz);
+        fold_ln(x.f1, 0, T(p + ".fc1.weight"), F, d, 1.0f, T(p + ".final_layer_norm.weight"), T(p + ".final_layer_norm.bias"),
+                T(p + ".fc1.bias"), s1.data(), c1.data());
+        x.f1b = st.put_f32(c1.data(), F);
+        x.f1s = st.put_f32(s1.data(), F);
         x.f2 = st.put_mat(T(p + ".fc2.weight"), d, F, F);
         x.f2b = st.put_f32(T(p + ".fc2.bias"), d);
         x.l1w = st.put_f32(T(p + ".self_attn_layer_norm.weight"), d);
@@ -487,6 +511,12 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     }
     size_t o_ckvb = st.put_f32(ckvb.data(), ckvb.size());
     size_t o_dlnw = st.put_f32(T(dd + ".layer_norm.weight"), d), o_dlnb = st.put_f32(T(dd + ".layer_norm.bias"), d);
+    // LM head = tied embedding with the final LayerNorm folded in (a second copy: the plain one stays the lookup table)
+    size_t o_lmw = st.reserve((size_t)c.vocab * d * m->esz);
+    std::vector<float> lms(c.vocab), lmc(c.vocab);
+    fold_ln(o_lmw, 0, T(dd + ".embed_tokens.weight"), c.vocab, d, 1.0f, T(dd + ".layer_norm.weight"), T(dd + ".layer_norm.bias"), nullptr,
+            lms.data(), lmc.data());
+    size_t o_lms = st.put_f32(lms.data(), c.vocab), o_lmc = st.put_f32(lmc.data(), c.vocab);
     // log-mel tables
     std::vector<double> tw;
     std::vector<float> win, fbT;
@@ -527,10 +557,11 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
         DecOff& x = dof[i];
         m->dec[i] = DecLayerDev{P(x.qkv), P(x.o), P(x.cq), P(x.co), P(x.f1), P(x.f2), PF(x.qkvb), PF(x.ob), PF(x.cqb),
                                 PF(x.cob), PF(x.f1b), PF(x.f2b), PF(x.l1w), PF(x.l1b), PF(x.l2w), PF(x.l2b), PF(x.l3w),
-                                PF(x.l3b)};
+                                PF(x.l3b), PF(x.qkvs), PF(x.cqs), PF(x.f1s)};
     }
     m->cross_kv_w = P(o_ckv); m->cross_kv_b = PF(o_ckvb);
     m->dec_ln_w = PF(o_dlnw); m->dec_ln_b = PF(o_dlnb);
+    m->lm_w = P(o_lmw); m->lm_s = PF(o_lms); m->lm_c = PF(o_lmc);
     m->mel_tw = (double*)P(o_tw); m->mel_win = PF(o_win); m->mel_fbT = PF(o_fb);
     *out = m;
     return WH_OK;
