@@ -48,6 +48,16 @@ int main(int argc, char** argv) {
         SkinnyArgs p; p.W = W; p.bias = bias; p.M = B; p.N = d; p.K = d; p.X = X; p.x_mpad = 64; p.R = xres; p.ldr = d; p.C = xres; p.ldc = d; p.xslab_out = C1; p.stats_out = part;
         printf("dec_gemm stats producer N=512 : %.2f us\n", time_chain(s, 200, [&]() { wh_launch_dec_gemm(s, prec, true, p); }));
     }
+    {   // encoder-shaped GEMMs: M = B*1500 rows
+        const int M = B * 1500;
+        void* A = dmalloc((size_t)M * 2048 * 2, 0); void* Wt = dmalloc((size_t)2048 * 2048 * 2); void* Cc = dmalloc((size_t)M * 2048 * 4);
+        for (auto nk : std::vector<std::pair<int, int>>{{512, 512}, {1024, 512}, {2048, 512}, {512, 2048}}) {
+            GemmArgs g; g.A = A; g.lda = nk.second; g.W = Wt; g.ldw = nk.second; g.C = Cc; g.ldc = nk.first; g.bias = bias; g.bias_mode = 1;
+            g.M = M; g.N = nk.first; g.K = nk.second;
+            double us = time_chain(s, 10, [&]() { wh_launch_gemm(s, prec, false, g); });
+            printf("enc gemm M=%d N=%4d K=%4d : %.1f us  %.0f TF/s\n", M, nk.first, nk.second, us, 2.0 * M * nk.first * nk.second / us / 1e6);
+        }
+    }
     {   // LM head
         SkinnyArgs a; a.W = W; a.X = X; a.x_mpad = 64; a.M = B; a.N = V; a.K = d; a.pos_p = pos; a.n_prompt = 1;
         a.mask_first = (unsigned*)dmalloc(V / 8 + 64); a.mask_base = a.mask_first; a.part_val = (float*)dmalloc((size_t)64 * 4096 * 4); a.part_idx = (int*)dmalloc((size_t)64 * 4096 * 4);

@@ -18,7 +18,7 @@ namespace {
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, const T* __restrict__ vT,
-                                                  T* __restrict__ out, int S, int d, int ldv) {
+                                                  T* __restrict__ out, int S, int d, int ldv, int n_heads) {
     constexpr int HD = WH_HEAD_DIM, KV = 64;
     constexpr int LD = HD + 16 / (int)sizeof(T);  // padded LDS row (elements): +16 B
     constexpr int EPC = 16 / (int)sizeof(T);
@@ -29,9 +29,24 @@ __global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, cons
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fl = lane & 15, fg = lane >> 4;
-    const int h = blockIdx.y;
-    const long clip = blockIdx.z;
-    const int q0 = blockIdx.x * 64 + wave * 16;
+    // XCD-aware work mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, so linear
+    // ids with equal (id % 8) share an L2.  All query tiles of one (clip, head) pair re-read the same K / V,
+    // so a pair's tiles are given ids with the same residue: id = slot * 8 + xcd, pair = (slot / nq) * 8 + xcd.
+    int qt, pair;
+    {
+        const int nq = (S + 63) / 64, npair = gridDim.x / nq, id = blockIdx.x;
+        if ((npair & 7) == 0) {
+            const int xcd = id & 7, slot = id >> 3;
+            pair = (slot / nq) * 8 + xcd;
+            qt = slot % nq;
+        } else {
+            pair = id / nq;
+            qt = id % nq;
+        }
+    }
+    const int h = pair % n_heads;
+    const long clip = pair / n_heads;
+    const int q0 = qt * 64 + wave * 16;
     const T* qkc = qk + clip * (long)S * 2 * d;
     const T* vc = vT + clip * (long)d * ldv + (long)h * HD * ldv;
 
@@ -137,9 +152,9 @@ __global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, cons
 
 void wh_launch_enc_attn(hipStream_t s, int prec, const void* qk, const void* vT, void* out, int n_clips, int S, int d,
                         int n_heads, int ldv) {
-    dim3 grid((S + 63) / 64, n_heads, n_clips);
+    dim3 grid(((S + 63) / 64) * n_heads * n_clips);
     if (prec == WH_PREC_F32)
-        hipLaunchKernelGGL(k_enc_attn<float>, grid, dim3(256), 0, s, (const float*)qk, (const float*)vT, (float*)out, S, d, ldv);
+        hipLaunchKernelGGL(k_enc_attn<float>, grid, dim3(256), 0, s, (const float*)qk, (const float*)vT, (float*)out, S, d, ldv, n_heads);
     else
-        hipLaunchKernelGGL(k_enc_attn<bf16>, grid, dim3(256), 0, s, (const bf16*)qk, (const bf16*)vT, (bf16*)out, S, d, ldv);
+        hipLaunchKernelGGL(k_enc_attn<bf16>, grid, dim3(256), 0, s, (const bf16*)qk, (const bf16*)vT, (bf16*)out, S, d, ldv, n_heads);
 }

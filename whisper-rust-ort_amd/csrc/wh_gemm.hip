@@ -2,6 +2,7 @@
 //
 //   C[m][n] = act( sum_k A[m][k] * W[n][k] + bias ) + R[m][n]
 //
+// K must be a multiple of 64 (bf16) / 32 (f32).
 // Both operands are k-contiguous (activations row-major, weights in torch Linear [out][in]
 // layout), which is exactly the 8-consecutive-k-per-lane MFMA fragment, so tiles go global → LDS →
 // registers with 16-byte accesses and no transposes.  The MFMA is issued with the WEIGHT tile as
@@ -21,20 +22,21 @@
 
 namespace {
 
-template <typename T> struct Ldk;               // LDS row stride (elements) for a 32-deep k-slab
-template <> struct Ldk<bf16> { static constexpr int v = 40; };   // 80 B rows
-template <> struct Ldk<float> { static constexpr int v = 36; };  // 144 B rows
+template <typename T> struct Tile;  // K-step depth and LDS row stride (elements) per compute dtype
+template <> struct Tile<bf16> { static constexpr int BK = 64, LDK = 72; };   // 144 B rows
+template <> struct Tile<float> { static constexpr int BK = 32, LDK = 36; };  // 144 B rows
 
 template <typename T, typename TO, int BM, int BN>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
-    constexpr int BK = 32;
-    constexpr int LDK = Ldk<T>::v;
-    constexpr int CPR = BK * (int)sizeof(T) / 16;        // 16-B chunks per tile row: 4 (bf16) / 8 (f32)
+    constexpr int BK = Tile<T>::BK, LDK = Tile<T>::LDK;
+    constexpr int CPR = BK * (int)sizeof(T) / 16;        // 16-B chunks per tile row (8)
     constexpr int EPC = 16 / (int)sizeof(T);             // elements per chunk
     constexpr int A_CH = BM * CPR / 256, W_CH = BN * CPR / 256;
     constexpr int TM = BM / 32, TN = BN / 32;            // 16x16 tiles per wave (2x2 waves)
-    __shared__ __attribute__((aligned(16))) T As[BM * LDK];
-    __shared__ __attribute__((aligned(16))) T Ws[BN * LDK];
+    // two LDS buffers per operand: slab k+1 is written while slab k is being consumed, one barrier per slab
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* As = reinterpret_cast<T*>(smem_raw);              // [2][BM][LDK]
+    T* Ws = As + 2 * BM * LDK;                           // [2][BN][LDK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -77,29 +79,43 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     for (int i = 0; i < A_CH; i++) a_reg[i] = *reinterpret_cast<const u32x4*>(a_src[i]);
 #pragma unroll
     for (int i = 0; i < W_CH; i++) w_reg[i] = *reinterpret_cast<const u32x4*>(w_src[i]);
+#pragma unroll
+    for (int i = 0; i < A_CH; i++) *reinterpret_cast<u32x4*>(&As[a_dst[i]]) = a_reg[i];
+#pragma unroll
+    for (int i = 0; i < W_CH; i++) *reinterpret_cast<u32x4*>(&Ws[w_dst[i]]) = w_reg[i];
+    __syncthreads();
 
     const int nk = g.K / BK;
     for (int kt = 0; kt < nk; kt++) {
-#pragma unroll
-        for (int i = 0; i < A_CH; i++) *reinterpret_cast<u32x4*>(&As[a_dst[i]]) = a_reg[i];
-#pragma unroll
-        for (int i = 0; i < W_CH; i++) *reinterpret_cast<u32x4*>(&Ws[w_dst[i]]) = w_reg[i];
-        __syncthreads();
-        if (kt + 1 < nk) {  // next slab's global loads fly under this slab's MFMAs
+        const T* Ac = As + (kt & 1) * BM * LDK;
+        const T* Wc = Ws + (kt & 1) * BN * LDK;
+        const bool more = kt + 1 < nk;
+        if (more) {  // next slab's global loads fly under this slab's MFMAs
 #pragma unroll
             for (int i = 0; i < A_CH; i++) a_reg[i] = *reinterpret_cast<const u32x4*>(a_src[i] + (long)(kt + 1) * BK);
 #pragma unroll
             for (int i = 0; i < W_CH; i++) w_reg[i] = *reinterpret_cast<const u32x4*>(w_src[i] + (long)(kt + 1) * BK);
         }
-        typename FragT<T>::type af[TM], wf[TN];
 #pragma unroll
-        for (int i = 0; i < TM; i++) af[i] = load_frag<T>(&As[(wr * (BM / 2) + i * 16 + fl) * LDK + fg * 8]);
+        for (int ks = 0; ks < BK / 32; ks++) {
+            typename FragT<T>::type af[TM], wf[TN];
 #pragma unroll
-        for (int j = 0; j < TN; j++) wf[j] = load_frag<T>(&Ws[(wc * (BN / 2) + j * 16 + fl) * LDK + fg * 8]);
+            for (int i = 0; i < TM; i++) af[i] = load_frag<T>(&Ac[(wr * (BM / 2) + i * 16 + fl) * LDK + ks * 32 + fg * 8]);
 #pragma unroll
-        for (int i = 0; i < TM; i++)
+            for (int j = 0; j < TN; j++) wf[j] = load_frag<T>(&Wc[(wc * (BN / 2) + j * 16 + fl) * LDK + ks * 32 + fg * 8]);
 #pragma unroll
-            for (int j = 0; j < TN; j++) mma16(acc[i][j], wf[j], af[i]);  // D rows = n, cols = m
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) mma16(acc[i][j], wf[j], af[i]);  // D rows = n, cols = m
+        }
+        if (more) {
+            T* An = As + ((kt + 1) & 1) * BM * LDK;
+            T* Wn = Ws + ((kt + 1) & 1) * BN * LDK;
+#pragma unroll
+            for (int i = 0; i < A_CH; i++) *reinterpret_cast<u32x4*>(&An[a_dst[i]]) = a_reg[i];
+#pragma unroll
+            for (int i = 0; i < W_CH; i++) *reinterpret_cast<u32x4*>(&Wn[w_dst[i]]) = w_reg[i];
+        }
         __syncthreads();
     }
 
@@ -202,12 +218,17 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
 template <typename T, typename TO>
 void launch_gemm_t(hipStream_t s, const GemmArgs& g) {
     const long blocks128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;
+    constexpr int LDK = Tile<T>::LDK;
     if (blocks128 >= 192) {
         dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, g.batch);
-        hipLaunchKernelGGL((k_gemm<T, TO, 128, 128>), grid, dim3(256), 0, s, g);
+        const size_t sm = (size_t)2 * (128 + 128) * LDK * sizeof(T);
+        static bool once = (hipFuncSetAttribute((const void*)k_gemm<T, TO, 128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm), true);
+        (void)once;
+        hipLaunchKernelGGL((k_gemm<T, TO, 128, 128>), grid, dim3(256), sm, s, g);
     } else {
         dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, g.batch);
-        hipLaunchKernelGGL((k_gemm<T, TO, 64, 64>), grid, dim3(256), 0, s, g);
+        const size_t sm = (size_t)2 * (64 + 64) * LDK * sizeof(T);
+        hipLaunchKernelGGL((k_gemm<T, TO, 64, 64>), grid, dim3(256), sm, s, g);
     }
 }
 
