@@ -3,9 +3,16 @@
 // Stands in for the MatMul→Softmax→MatMul subgraph of every encoder layer of encoder_model.onnx
 // (run via reference src/main.rs:703; definition [3P] modeling_whisper.py eager_attention_forward
 // :215-238 with q pre-scaled by head_dim^-0.5 at :309 — the scale is folded into W_q/b_q at load).
-// The [S,S] score matrix is never written: one workgroup owns 64 query rows of one (clip, head),
-// four waves x 16 rows; K and V^T tiles of 64 keys are staged in LDS once per workgroup and
-// consumed as MFMA operands; softmax runs online in f32 registers.
+// The [S,S] score matrix is never written.  One workgroup = 128 query rows of one (clip, head): four
+// waves x 32 rows.  Per 64-key tile (K and V^T staged in LDS, double buffered, one barrier per tile):
+//   S^T = K · Q^T      (MFMA row operand = K rows from LDS, column operand = Q fragments in registers)
+//         → every lane holds 16 scores of ONE query column: the online-softmax state (max, sum) is
+//           lane-local apart from one cross-lane max over the four lane groups;
+//   O^T += V^T · P^T   (row operand = V^T from LDS, column operand = P^T straight from the score
+//           registers: the k-slot ↔ key assignment of the MFMA is permuted identically on both
+//           operands, so P never goes through LDS and needs no transpose)
+//         → the rescale factor of a query is lane-local too, and each lane finally stores 4 consecutive
+//           features of its query row.
 //
 // Layouts (T = bf16 or f32):
 //   qk : [clip][S][2*d]      q at column h*64, k at column d + h*64           (QK projection output)
@@ -16,25 +23,39 @@
 
 namespace {
 
+template <typename T> struct HalfFrag;  // 4 consecutive elements
+template <> struct HalfFrag<bf16> { typedef bf16x4 type; };
+template <> struct HalfFrag<float> { typedef f32x4 type; };
+
+__device__ __forceinline__ bf16x8 join_half(bf16x4 a, bf16x4 b) { return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+__device__ __forceinline__ f32x8 join_half(f32x4 a, f32x4 b) { return f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+__device__ __forceinline__ void pack_p(bf16x8& f, const f32x4& a, const f32x4& b) {
+    f = bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+}
+__device__ __forceinline__ void pack_p(f32x8& f, const f32x4& a, const f32x4& b) { f = f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, const T* __restrict__ vT,
                                                   T* __restrict__ out, int S, int d, int ldv, int n_heads) {
-    constexpr int HD = WH_HEAD_DIM, KV = 64;
+    constexpr int HD = WH_HEAD_DIM, KV = 64, QB = 128;
     constexpr int LD = HD + 16 / (int)sizeof(T);  // padded LDS row (elements): +16 B
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int CPR = HD / EPC;                 // 16-B chunks per 64-element row
-    __shared__ __attribute__((aligned(16))) T Ks[KV * LD];       // [key][e]
-    __shared__ __attribute__((aligned(16))) T Vs[HD * LD];       // [e][key]
-    __shared__ __attribute__((aligned(16))) T Ps[4 * 16 * LD];   // per wave [q][key]
+    constexpr int NCH = KV * CPR / 256;           // staging chunks per thread per operand: 2 (bf16) / 4 (f32)
+    typedef typename FragT<T>::type frag_t;
+    typedef typename HalfFrag<T>::type half_t;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* Ks = reinterpret_cast<T*>(smem_raw);       // [2][KV][LD]   rows = keys
+    T* Vs = Ks + 2 * KV * LD;                     // [2][HD][LD]   rows = features, columns = keys
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fl = lane & 15, fg = lane >> 4;
-    // XCD-aware work mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, so linear
-    // ids with equal (id % 8) share an L2.  All query tiles of one (clip, head) pair re-read the same K / V,
-    // so a pair's tiles are given ids with the same residue: id = slot * 8 + xcd, pair = (slot / nq) * 8 + xcd.
+    // XCD-aware work mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, so linear ids
+    // with equal (id % 8) share an L2; the query blocks of one (clip, head) pair re-read the same K / V.
     int qt, pair;
     {
-        const int nq = (S + 63) / 64, npair = gridDim.x / nq, id = blockIdx.x;
+        const int nq = (S + QB - 1) / QB, npair = gridDim.x / nq, id = blockIdx.x;
         if ((npair & 7) == 0) {
             const int xcd = id & 7, slot = id >> 3;
             pair = (slot / nq) * 8 + xcd;
@@ -46,105 +67,138 @@ __global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, cons
     }
     const int h = pair % n_heads;
     const long clip = pair / n_heads;
-    const int q0 = qt * 64 + wave * 16;
+    const int q0 = qt * QB + wave * 32;
     const T* qkc = qk + clip * (long)S * 2 * d;
     const T* vc = vT + clip * (long)d * ldv + (long)h * HD * ldv;
 
-    // Q fragments: A[i = q (fl)][k = e]
-    typename FragT<T>::type qf[2];
-    {
-        int q = q0 + fl;
+    // Q^T column operands: lane (fl = query, fg) holds Q[q][32*ks + 8*fg ..]
+    frag_t qf[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        int q = q0 + 16 * u + fl;
         if (q > S - 1) q = S - 1;
         const T* qp = qkc + (long)q * 2 * d + h * HD;
-        qf[0] = load_frag<T>(qp + fg * 8);
-        qf[1] = load_frag<T>(qp + 32 + fg * 8);
+        qf[u][0] = load_frag<T>(qp + fg * 8);
+        qf[u][1] = load_frag<T>(qp + 32 + fg * 8);
     }
-    f32x4 o[4];
+    f32x4 o[2][4];   // O^T: rows e = 16*te + 4*fg + r, column q = fl
+    float mrow[2], lsum[2];
 #pragma unroll
-    for (int t = 0; t < 4; t++) o[t] = f32x4{0, 0, 0, 0};
-    float mrow[4], lrow[4];
+    for (int u = 0; u < 2; u++) {
+        mrow[u] = -INFINITY;
+        lsum[u] = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 4; r++) { mrow[r] = -INFINITY; lrow[r] = 0.0f; }
+        for (int te = 0; te < 4; te++) o[u][te] = f32x4{0, 0, 0, 0};
+    }
 
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    T* Pw = Ps + wave * 16 * LD;
-    for (int k0 = 0; k0 < S; k0 += KV) {
-        __syncthreads();  // previous tile fully consumed
-        for (int c = tid; c < KV * CPR; c += 256) {
-            int row = c / CPR, col = (c % CPR) * EPC;
-            int key = k0 + row;
+    // staging: thread → (row, 16-B chunk) of the K tile and of the V^T tile
+    int st_row[NCH], st_col[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const int c = tid + i * 256;
+        st_row[i] = c / CPR;
+        st_col[i] = (c % CPR) * EPC;
+    }
+    u32x4 kreg[NCH], vreg[NCH];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            int key = k0 + st_row[i];
             if (key > S - 1) key = S - 1;
-            *reinterpret_cast<u32x4*>(&Ks[row * LD + col]) =
-                *reinterpret_cast<const u32x4*>(qkc + (long)key * 2 * d + d + h * HD + col);
-            // V^T rows are e, columns keys k0..k0+63 (ldv >= S rounded up to 64, zero padded)
-            *reinterpret_cast<u32x4*>(&Vs[row * LD + col]) =
-                *reinterpret_cast<const u32x4*>(vc + (long)row * ldv + k0 + col);
+            kreg[i] = *reinterpret_cast<const u32x4*>(qkc + (long)key * 2 * d + d + h * HD + st_col[i]);
+            vreg[i] = *reinterpret_cast<const u32x4*>(vc + (long)st_row[i] * ldv + k0 + st_col[i]);  // ldv covers k0+63, zero padded
         }
-        __syncthreads();
-        // S tile: D[i = q][j = key]; rows i = 4*fg + r, col j = fl
-        f32x4 sc[4];
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            *reinterpret_cast<u32x4*>(&Ks[(buf * KV + st_row[i]) * LD + st_col[i]]) = kreg[i];
+            *reinterpret_cast<u32x4*>(&Vs[(buf * HD + st_row[i]) * LD + st_col[i]]) = vreg[i];
+        }
+    };
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    const int nt = (S + KV - 1) / KV;
+    for (int it = 0; it < nt; it++) {
+        const int cur = it & 1, k0 = it * KV;
+        if (it + 1 < nt) load_tile(k0 + KV);  // flies under this tile's MFMAs
+        const T* Kc = Ks + cur * KV * LD;
+        const T* Vc = Vs + cur * HD * LD;
+        // ---- S^T[key][q]: rows key = 16*t + 4*fg + r, column q = fl ------------------------------------
+        f32x4 sc[2][4];
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            sc[t] = f32x4{0, 0, 0, 0};
+            const frag_t k0f = load_frag<T>(&Kc[(t * 16 + fl) * LD + fg * 8]);
+            const frag_t k1f = load_frag<T>(&Kc[(t * 16 + fl) * LD + 32 + fg * 8]);
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                typename FragT<T>::type kf = load_frag<T>(&Ks[(t * 16 + fl) * LD + ks * 32 + fg * 8]);
-                mma16(sc[t], qf[ks], kf);
+            for (int u = 0; u < 2; u++) {
+                sc[u][t] = f32x4{0, 0, 0, 0};
+                mma16(sc[u][t], k0f, qf[u][0]);
+                mma16(sc[u][t], k1f, qf[u][1]);
             }
         }
-        float alpha[4];
+        // ---- online softmax, lane-local per query column -----------------------------------------------
+        frag_t pf[2][2];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
+        for (int u = 0; u < 2; u++) {
             float mx = -INFINITY;
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                if (k0 + t * 16 + fl >= S) sc[t][r] = -INFINITY;
-                mx = fmaxf(mx, sc[t][r]);
-            }
+            for (int t = 0; t < 4; t++)
 #pragma unroll
-            for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-            const float mn = fmaxf(mrow[r], mx);
-            alpha[r] = __expf(mrow[r] - mn);
+                for (int r = 0; r < 4; r++) {
+                    if (k0 + t * 16 + 4 * fg + r >= S) sc[u][t][r] = -INFINITY;
+                    mx = fmaxf(mx, sc[u][t][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(mrow[u], mx);
+            const float alpha = __expf(mrow[u] - mn);
             float rs = 0.0f;
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                float p = __expf(sc[t][r] - mn);
-                sc[t][r] = p;
-                rs += p;
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float p = __expf(sc[u][t][r] - mn);
+                    sc[u][t][r] = p;
+                    rs += p;
+                }
+            lsum[u] = lsum[u] * alpha + rs;  // this lane group's share; the four groups are added at the end
+            mrow[u] = mn;
+#pragma unroll
+            for (int te = 0; te < 4; te++) {
+                o[u][te][0] *= alpha; o[u][te][1] *= alpha; o[u][te][2] *= alpha; o[u][te][3] *= alpha;
             }
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) rs += __shfl_xor(rs, off);
-            lrow[r] = lrow[r] * alpha[r] + rs;
-            mrow[r] = mn;
+            // P^T column operands: k-slot 8*fg + j ↔ key 16*t0 + 4*fg + j (j < 4), 16*t1 + 4*fg + j - 4 (j >= 4)
+            pack_p(pf[u][0], sc[u][0], sc[u][1]);
+            pack_p(pf[u][1], sc[u][2], sc[u][3]);
         }
-        // P to LDS as [q][key], then back as the row operand of P·V
+        // ---- O^T[e][q] += V^T[e][keys] P^T[keys][q], same k-slot ↔ key assignment on the row operand ----
 #pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) Pw[(4 * fg + r) * LD + t * 16 + fl] = cvt_out<T>(sc[t][r]);
-        __syncthreads();
-        typename FragT<T>::type pf[2];
-        pf[0] = load_frag<T>(&Pw[fl * LD + fg * 8]);
-        pf[1] = load_frag<T>(&Pw[fl * LD + 32 + fg * 8]);
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) o[t][r] *= alpha[r];
+        for (int te = 0; te < 4; te++) {
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
-                typename FragT<T>::type vf = load_frag<T>(&Vs[(t * 16 + fl) * LD + ks * 32 + fg * 8]);
-                mma16(o[t], pf[ks], vf);  // D[i = q][j = e]
+                const T* vp = &Vc[(te * 16 + fl) * LD + 32 * ks + 4 * fg];
+                const frag_t vf = join_half(*reinterpret_cast<const half_t*>(vp), *reinterpret_cast<const half_t*>(vp + 16));
+                mma16(o[0][te], vf, pf[0][ks]);
+                mma16(o[1][te], vf, pf[1][ks]);
             }
         }
+        if (it + 1 < nt) store_tile(cur ^ 1);
+        __syncthreads();
     }
     T* oc = out + clip * (long)S * d;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int q = q0 + 4 * fg + r;
+    for (int u = 0; u < 2; u++) {
+        float l = lsum[u];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const int q = q0 + 16 * u + fl;
         if (q >= S) continue;
-        const float inv = 1.0f / lrow[r];
+        const float inv = 1.0f / l;
 #pragma unroll
-        for (int t = 0; t < 4; t++) oc[(long)q * d + h * HD + t * 16 + fl] = cvt_out<T>(o[t][r] * inv);
+        for (int te = 0; te < 4; te++)
+            store4(oc + (long)q * d + h * HD + te * 16 + 4 * fg, o[u][te][0] * inv, o[u][te][1] * inv, o[u][te][2] * inv, o[u][te][3] * inv);
     }
 }
 
@@ -152,9 +206,14 @@ __global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, cons
 
 void wh_launch_enc_attn(hipStream_t s, int prec, const void* qk, const void* vT, void* out, int n_clips, int S, int d,
                         int n_heads, int ldv) {
-    dim3 grid(((S + 63) / 64) * n_heads * n_clips);
-    if (prec == WH_PREC_F32)
-        hipLaunchKernelGGL(k_enc_attn<float>, grid, dim3(256), 0, s, (const float*)qk, (const float*)vT, (float*)out, S, d, ldv, n_heads);
-    else
-        hipLaunchKernelGGL(k_enc_attn<bf16>, grid, dim3(256), 0, s, (const bf16*)qk, (const bf16*)vT, (bf16*)out, S, d, ldv, n_heads);
+    dim3 grid(((S + 127) / 128) * n_heads * n_clips);
+    if (prec == WH_PREC_F32) {
+        const size_t sm = (size_t)2 * 2 * 64 * (64 + 4) * 4;  // 69.6 KB: above the default dynamic-LDS limit
+        static bool once = (hipFuncSetAttribute((const void*)k_enc_attn<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm), true);
+        (void)once;
+        hipLaunchKernelGGL(k_enc_attn<float>, grid, dim3(256), sm, s, (const float*)qk, (const float*)vT, (float*)out, S, d, ldv, n_heads);
+    } else {
+        const size_t sm = (size_t)2 * 2 * 64 * (64 + 8) * 2;
+        hipLaunchKernelGGL(k_enc_attn<bf16>, grid, dim3(256), sm, s, (const bf16*)qk, (const bf16*)vT, (bf16*)out, S, d, ldv, n_heads);
+    }
 }
