@@ -38,8 +38,12 @@ int main(int argc, char** argv) {
         SkinnyArgs a; a.W = W; a.bias = bias; a.M = B; a.N = nk.first; a.K = nk.second; a.X = X; a.x_mpad = 64;
         const bool res = nk.first == d;
         if (res) { a.R = xres; a.ldr = d; a.C = xres; a.ldc = d; } else { a.C = C1; a.c_mpad = 64; }
-        double us = time_chain(s, 200, [&]() { wh_launch_dec_gemm(s, prec, res, a); });
-        printf("dec_gemm M=%d N=%4d K=%4d : %.2f us\n", B, nk.first, nk.second, us);
+        for (int dm : {4, 2, 1}) {
+            wh_dbg_mt = dm;
+            double us = time_chain(s, 200, [&]() { wh_launch_dec_gemm(s, prec, res, a); });
+            printf("dec_gemm M=%d N=%4d K=%4d rows/wg=%d : %.2f us\n", B, nk.first, nk.second, dm * 16, us);
+        }
+        wh_dbg_mt = 0;
     }
     {   // LN-folded consumer + stats-producing residual GEMM
         float* part = (float*)dmalloc(32 * 64 * 2 * 4); float* sv = (float*)dmalloc(F * 4);

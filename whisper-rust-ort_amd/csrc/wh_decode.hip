@@ -31,6 +31,7 @@
 // tuning knobs (tools/microbench.cpp flips them; product code leaves the defaults)
 int wh_dbg_cross_unroll = 4;
 int wh_dbg_lm_blocks_per_cu = 2;
+int wh_dbg_mt = 0;
 
 namespace {
 
@@ -679,7 +680,13 @@ void set_max_smem(K kernel, size_t bytes) {
 template <typename T, typename TO, int NW>
 void launch_dec_gemm_mt(hipStream_t s, const SkinnyArgs& a) {
     const int n_tiles = (a.N + 15) / 16;
-    const int mt = std::min(4, (a.M + 15) / 16);
+    // rows per workgroup: 64, or 32 when K is deep (every workgroup pulls its rows of X through L2; halving
+    // them costs a second read of the 16-column weight tile but doubles the workgroups sharing the load)
+    // measured (tools/microbench.cpp, M = 64): N = 512 → 16 rows best (2.6 vs 3.7 us), N = 1536 / 2048 → 32 rows
+    // (2.95 vs 3.5 us), K = 2048 → 16 rows (4.6 vs 7.5 us): aim for >= 128 workgroups
+    int mt_cap = (NW == 8 || n_tiles <= 48) ? 1 : 2;
+    if (wh_dbg_mt > 0) mt_cap = wh_dbg_mt;  // microbench override
+    const int mt = std::min(mt_cap, (a.M + 15) / 16);
     const size_t sm = (size_t)NW * mt * 64 * 16 + (size_t)4 * mt * 16 * 2 * 4;
     dim3 grid(n_tiles, (a.M + 16 * mt - 1) / (16 * mt));
     switch (mt) {
