@@ -189,6 +189,16 @@ def main() -> None:
     run_step()
     breakdown = {k: {"ms": sum(cx.profile_get()[k]["ms"] for cx in ctxs) / a.streams,
                      "launches": sum(cx.profile_get()[k]["launches"] for cx in ctxs)} for k in wb.KG_NAMES}
+    # BASELINE configs[1] (batch = 1 clip on one GPU): per-clip end-to-end latency, untimed extra
+    b1_ms = []
+    if rank == 0:
+        ctx1 = wb.Context(model, 1)
+        for i in range(6):
+            t1 = time.perf_counter()
+            ctx1.transcribe_batch_device(d_pcm + (i % a.clips) * 480000 * 4, 1, params)
+            if i:
+                b1_ms.append((time.perf_counter() - t1) * 1e3)
+        ctx1.close()
     # timed region: only the dominant kernel (decoder cross-attention) is bracketed by HIP events
     for cx in ctxs:
         cx.profile_enable(True if a.profile_all else ["dec_cross_attn"])
@@ -257,6 +267,8 @@ def main() -> None:
             "rtf": elapsed / audio_s,   # reference definition: latency / duration (src/main.rs:1191)
             "clips_per_s": a.clips * a.steps * world / elapsed,
             "p95_ms_per_clip": float(np.percentile(np.asarray(lat) * 1e3, 95)),  # every clip of a batch completes with its batch
+            "batch1": {"p95_ms_per_clip": float(np.percentile(b1_ms, 95)), "median_ms_per_clip": float(np.median(b1_ms)),
+                       "rtfx": 30e3 / float(np.median(b1_ms)), "note": "BASELINE configs[1]: one clip per call on one GPU"},
             "stage_ms_per_step": {k: v / a.steps * 1e3 for k, v in stage.items()},
             "kernel_group_ms_per_step": {k: round(v["ms"], 3) for k, v in breakdown.items()},
             "kernel_group_launches": {k: v["launches"] for k, v in breakdown.items()},

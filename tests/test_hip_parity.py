@@ -326,3 +326,30 @@ def test_bf16_batch_is_deterministic_and_permutation_invariant(gpu):
     for j, i in enumerate(perm):
         assert c[j].tolist() == a[i].tolist()
     assert all(len(t) == len(prompt) + 16 for t in a)   # EOT suppressed → full length
+
+
+# ------------------------------------------------------------------------------------------------
+# full-size properties (BASELINE configs[2] shard: whisper-base, bf16, 64 clips per batch, 128 tokens)
+# ------------------------------------------------------------------------------------------------
+def test_base_bf16_full_batch_properties(gpu):
+    """At the benchmark's own size the oracle is too slow to be the checker, so size-independent properties
+    are: the 64-clip batch equals the same clips run in two 32-clip batches and one by one (clips are
+    independent units), duplicates give identical rows, the run is deterministic, and with EOT suppressed
+    every clip emits exactly max_new_tokens."""
+    b64 = bundle("base", 1234, wb.WH_PREC_BF16, max_batch=64)
+    prompt, eot = small_prompt(b64.dims)
+    clips = [ms.synth_clip(100 + i) for i in range(62)] + [ms.synth_clip(100), ms.synth_clip(101)]   # two duplicates
+    params = wb.DecodeParams(prompt, 128, eot, [eot])
+    full = b64.ctx.transcribe_batch(clips, params)
+    again = b64.ctx.transcribe_batch(clips, params)
+    assert [t.tolist() for t in full] == [t.tolist() for t in again]
+    assert all(len(t) == len(prompt) + 128 for t in full) and all(eot not in t[len(prompt):] for t in full)
+    assert full[62].tolist() == full[0].tolist() and full[63].tolist() == full[1].tolist()
+    halves = b64.ctx.transcribe_batch(clips[:32], params) + b64.ctx.transcribe_batch(clips[32:], params)
+    assert [t.tolist() for t in halves] == [t.tolist() for t in full]
+    for i in (0, 17, 63):
+        assert b64.ctx.transcribe_batch([clips[i]], params)[0].tolist() == full[i].tolist()
+    # free-running (EOT allowed): each row is a prefix-consistent cut of the suppressed run up to its EOT
+    free = b64.ctx.transcribe_batch(clips[:8], wb.DecodeParams(prompt, 128, eot))
+    for t in free:
+        assert len(t) <= len(prompt) + 128 and (eot not in t[len(prompt):-1].tolist())

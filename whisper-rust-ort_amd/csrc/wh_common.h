@@ -96,6 +96,30 @@ __device__ __forceinline__ float dpp_group_sum(float v) {
     return v;
 }
 
+// Full-wave (64-lane) sum / max: DPP inside each 16-lane row, then the four row results through SGPRs
+// (v_readlane) — no LDS crossbar (ds_bpermute) round trips.
+__device__ __forceinline__ float dpp_wave_sum(float v) {
+    v = dpp_group_sum<16>(v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48)));
+}
+__device__ __forceinline__ float dpp_max16(float v) {
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+    return v;
+}
+__device__ __forceinline__ float dpp_wave_max(float v) {
+    v = dpp_max16(v);
+    return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)),
+                       __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16))),
+                 fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)),
+                       __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48))));
+}
+
 typedef __attribute__((ext_vector_type(4))) unsigned wh_u32x4;
 // NOTE: hipcc (ROCm 7.2) miscompiles __builtin_bit_cast(bf16x2, <element of a uint vector>) — every
 // element resolves to element 0.  Going through memcpy produces the intended register moves.

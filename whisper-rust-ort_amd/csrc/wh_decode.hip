@@ -393,60 +393,89 @@ __global__ __launch_bounds__(256) void k_argmax_finish(const float* __restrict__
 }
 
 // ---- decoder self-attention, one position ([3P] :417-425, 468-475): one wave per (head, clip) ---
-// qkv: [B][3d] (q pre-scaled | k | v) of the current position; caches [B][H][TC][64].
+// qkv: [B][3d] (q pre-scaled | k | v) of the current position.
+// K cache [B][H][TC][64]  (lane j scores key j: its row is 8 x 16-byte loads, issued before anything else)
+// V cache [B][H][TC][64]  (lane e reads column e of every cached row: one 128-byte line per wave load)
+// The new k / v are appended (present.{i}.decoder.{key,value}) and used straight from registers.
 template <typename T>
 __global__ __launch_bounds__(64) void k_dec_self_attn(const T* __restrict__ qkv, T* __restrict__ kc,
                                                       T* __restrict__ vc, T* __restrict__ out,
                                                       const int* __restrict__ pos_p, int d, int n_heads, int tc,
                                                       int mpad) {
     constexpr int HD = WH_HEAD_DIM;
-    __shared__ float qs[HD];
-    __shared__ float sc[512];
+    constexpr int EPC = 16 / (int)sizeof(T);
+    typedef typename FragT<T>::type frag_t;
+    typedef __attribute__((ext_vector_type(EPC))) T vec_t;
+    __shared__ __attribute__((aligned(16))) float qs[HD];
+    __shared__ __attribute__((aligned(16))) float sc[512];
     const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x, pos = *pos_p;
     const T* row = qkv + (long)b * 3 * d;
     T* kcb = kc + ((long)b * n_heads + h) * tc * HD;
     T* vcb = vc + ((long)b * n_heads + h) * tc * HD;
+    // 1. the cached K rows of this lane's first two keys go in flight before anything else
+    frag_t kr[2][HD / 8];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int j = lane + 64 * i;
+        if (j < pos) {
+#pragma unroll
+            for (int e = 0; e < HD / 8; e++) kr[i][e] = load_frag<T>(kcb + (long)j * HD + e * 8);
+        }
+    }
     const T kcur = row[d + h * HD + lane], vcur = row[2 * d + h * HD + lane];
-    kcb[(long)pos * HD + lane] = kcur;  // append: present.{i}.decoder.{key,value}
-    vcb[(long)pos * HD + lane] = vcur;
     qs[lane] = cvt_in<T>(row[h * HD + lane]);
+    kcb[(long)pos * HD + lane] = kcur;
+    vcb[(long)pos * HD + lane] = vcur;
     __syncthreads();
-    // scores over the past (from the cache) — each lane owns keys lane, lane+64, ...
+    // 2. scores of the past: lane owns keys lane, lane+64, ... (the first two already loaded)
     float mx = -INFINITY;
-    for (int j = lane; j < pos; j += 64) {
-        const T* kr = kcb + (long)j * HD;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int j = lane + 64 * i;
+        if (j < pos) {
+            float s = 0.0f;
+#pragma unroll
+            for (int e = 0; e < HD / 8; e++)
+#pragma unroll
+                for (int u = 0; u < 8; u++) s += qs[e * 8 + u] * (float)kr[i][e][u];
+            sc[j] = s;
+            mx = fmaxf(mx, s);
+        }
+    }
+    for (int j = lane + 128; j < pos; j += 64) {
         float s = 0.0f;
 #pragma unroll
-        for (int e = 0; e < HD; e += 8) {
-            typename FragT<T>::type kk = load_frag<T>(kr + e);
+        for (int e = 0; e < HD / 8; e++) {
+            const frag_t kk = load_frag<T>(kcb + (long)j * HD + e * 8);
 #pragma unroll
-            for (int u = 0; u < 8; u++) s += qs[e + u] * (float)kk[u];
+            for (int u = 0; u < 8; u++) s += qs[e * 8 + u] * (float)kk[u];
         }
         sc[j] = s;
         mx = fmaxf(mx, s);
     }
-    // the current position straight from registers
-    const float scur = wave_sum(qs[lane] * cvt_in<T>(kcur));
-    mx = fmaxf(wave_max(mx), scur);
-    __syncthreads();
+    const float scur = dpp_wave_sum(qs[lane] * cvt_in<T>(kcur));
+    mx = fmaxf(dpp_wave_max(mx), scur);
     float sum = 0.0f;
     for (int j = lane; j < pos; j += 64) {
-        float p = __expf(sc[j] - mx);
+        const float p = __expf(sc[j] - mx);
         sc[j] = p;
         sum += p;
     }
     const float pcur = __expf(scur - mx);
-    sum = wave_sum(sum) + pcur;
+    sum = dpp_wave_sum(sum) + pcur;
     __syncthreads();
-    float o0 = pcur * cvt_in<T>(vcur), o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
+    // 3. P·V: eight cached rows in flight at a time; probabilities are LDS broadcasts
+    float o = pcur * cvt_in<T>(vcur);
     int j = 0;
-    for (; j + 4 <= pos; j += 4) {
-        const float v0 = cvt_in<T>(vcb[(long)j * HD + lane]), v1 = cvt_in<T>(vcb[(long)(j + 1) * HD + lane]);
-        const float v2 = cvt_in<T>(vcb[(long)(j + 2) * HD + lane]), v3 = cvt_in<T>(vcb[(long)(j + 3) * HD + lane]);
-        o0 += sc[j] * v0; o1 += sc[j + 1] * v1; o2 += sc[j + 2] * v2; o3 += sc[j + 3] * v3;
+    for (; j + 8 <= pos; j += 8) {
+        T v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = vcb[(long)(j + u) * HD + lane];
+#pragma unroll
+        for (int u = 0; u < 8; u++) o += sc[j + u] * cvt_in<T>(v[u]);
     }
-    for (; j < pos; j++) o0 += sc[j] * cvt_in<T>(vcb[(long)j * HD + lane]);
-    out[slab_idx(b, h * HD + lane, mpad)] = cvt_out<T>(((o0 + o1) + (o2 + o3)) / sum);
+    for (; j < pos; j++) o += sc[j] * cvt_in<T>(vcb[(long)j * HD + lane]);
+    out[slab_idx(b, h * HD + lane, mpad)] = cvt_out<T>(o / sum);
 }
 
 // ---- decoder cross-attention, one position ([3P] :433-440, 478-491) -----------------------------
