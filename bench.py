@@ -117,6 +117,9 @@ def main() -> None:
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch1", action="store_true", help="skip the batch-1 latency side measurement (profiling runs)")
+    ap.add_argument("--test-single-device", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses device 0 and the gather goes over gloo")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group even for world size 1")
     ap.add_argument("--profile-all", action="store_true", help="event-time every kernel group in the timed region")
     a = ap.parse_args()
 
@@ -128,17 +131,27 @@ def main() -> None:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     dist = None
     backend = "none"
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        try:
-            dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL on ROCm
-            backend = "nccl"
-        except Exception:
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if a.test_single_device:
+            local_rank = 0
             dist.init_process_group("gloo", rank=rank, world_size=world)
             backend = "gloo"
+        else:
+            torch.cuda.set_device(local_rank)
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL on ROCm
+                backend = "nccl"
+                dist.barrier()
+            except Exception as e:  # RCCL unavailable: the result gather is tiny, gloo carries it
+                print(f"[bench] nccl init failed ({e}); falling back to gloo", file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                backend = "gloo"
 
     dims = ms.PRESETS[a.preset]
     prec = wb.WH_PREC_BF16 if a.precision == "bf16" else wb.WH_PREC_F32
