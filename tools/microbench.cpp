@@ -65,7 +65,8 @@ int main(int argc, char** argv) {
     {   // LM head
         SkinnyArgs a; a.W = W; a.X = X; a.x_mpad = 64; a.M = B; a.N = V; a.K = d; a.pos_p = pos; a.n_prompt = 1;
         a.mask_first = (unsigned*)dmalloc(V / 8 + 64); a.mask_base = a.mask_first; a.part_val = (float*)dmalloc((size_t)64 * 4096 * 4); a.part_idx = (int*)dmalloc((size_t)64 * 4096 * 4);
-        for (int bpc : {1, 2}) { wh_dbg_lm_blocks_per_cu = bpc; printf("lm_head M=%d blocks/cu=%d : %.2f us\n", B, bpc, time_chain(s, 50, [&]() { wh_launch_lm_head(s, prec, a); })); }
+        for (int lmt : {4, 2, 1}) for (int bpc : {1, 2, 4, 8}) { wh_dbg_lm_blocks_per_cu = bpc; wh_dbg_lm_mt = lmt; printf("lm_head M=%d rows/wg=%d blocks/cu=%d : %.2f us\n", B, lmt * 16, bpc, time_chain(s, 50, [&]() { wh_launch_lm_head(s, prec, a); })); }
+        wh_dbg_lm_blocks_per_cu = 2; wh_dbg_lm_mt = 4;
     }
     {   // cross attention: distinct K/V planes per "layer" so nothing is cache resident
         const int L = 6; const size_t plane = (size_t)B * S * d;

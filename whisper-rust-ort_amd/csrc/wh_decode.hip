@@ -31,6 +31,7 @@
 // tuning knobs (tools/microbench.cpp flips them; product code leaves the defaults)
 int wh_dbg_cross_unroll = 4;
 int wh_dbg_lm_blocks_per_cu = 2;
+int wh_dbg_lm_mt = 4;
 int wh_dbg_mt = 0;
 
 namespace {
@@ -754,12 +755,12 @@ void wh_launch_dec_embed(hipStream_t s, int prec, const void* tok_emb, const flo
 template <typename T>
 void launch_lm_head_t(hipStream_t s, const SkinnyArgs& a) {
     const int n_tiles = (a.N + 15) / 16;
-    int mt = std::min(4, (a.M + 15) / 16);
+    int mt = std::min(wh_dbg_lm_mt, (a.M + 15) / 16);
     auto lds = [&](int t) { return (size_t)t * 16 * a.K * sizeof(T) + (size_t)t * 16 * 2 * 4; };
     while (mt > 1 && lds(mt) > 150 * 1024) mt--;
     const size_t sm = lds(mt);
     const int per_cu = std::max<int>(1, (int)(150 * 1024 / sm));
-    dim3 grid(std::min((n_tiles + 3) / 4, 256 * std::min(per_cu, wh_dbg_lm_blocks_per_cu)), (a.M + 16 * mt - 1) / (16 * mt));
+    dim3 grid(std::min((n_tiles + 3) / 4, 256 * std::min(per_cu, wh_dbg_lm_blocks_per_cu) / ((a.M + 16 * mt - 1) / (16 * mt))), (a.M + 16 * mt - 1) / (16 * mt));
 #define WH_LM(MT_)                                                \
     {                                                             \
         auto kfn = k_lm_head<T, MT_>;                             \

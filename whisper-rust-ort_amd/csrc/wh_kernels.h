@@ -100,3 +100,4 @@ void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void
 extern int wh_dbg_cross_unroll;
 extern int wh_dbg_lm_blocks_per_cu;
 extern int wh_dbg_mt;
+extern int wh_dbg_lm_mt;
