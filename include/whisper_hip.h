@@ -164,9 +164,11 @@ int wh_transcribe_longform(wh_ctx* c, const float* pcm, size_t n_samples, double
 #define WH_KG_DEC_GEMM 4
 #define WH_KG_DEC_OTHER 5
 #define WH_KG_COUNT 6
-/* group_mask: bit g set → every launch of kernel group g is bracketed by hipEvents on the launch
- * stream (0 = off; while on, decode steps are launched eagerly instead of replaying the captured
- * hipGraph).  The totals of the last transcribe call come back as (milliseconds, launches) per group. */
+/* group_mask bits 0-15: bit g set → launches of kernel group g are bracketed by hipEvents on the launch
+ * stream (0 = off).  Bits 16-31: sampling stride S of the token loop — S <= 1: every decoder position is
+ * launched eagerly and timed; S > 1: only every S-th generated position is (the others replay the captured
+ * hipGraph, so the measurement barely perturbs the run).  The totals of the last transcribe call come back
+ * as (milliseconds, number of timed launches) per group. */
 int wh_profile_enable(wh_ctx* c, int group_mask);
 int wh_profile_get(const wh_ctx* c, double* ms /* [WH_KG_COUNT] */, int64_t* launches /* [WH_KG_COUNT] */);
 

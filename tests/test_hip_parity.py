@@ -353,3 +353,31 @@ def test_base_bf16_full_batch_properties(gpu):
     free = b64.ctx.transcribe_batch(clips[:8], wb.DecodeParams(prompt, 128, eot))
     for t in free:
         assert len(t) <= len(prompt) + 128 and (eot not in t[len(prompt):-1].tolist())
+
+
+def test_launch_modes_agree(gpu):
+    """The token loop has three launch modes — hipGraph replay (default), eager with per-launch events
+    (profile on), and sampled (graph replay with every stride-th position eager + timed).  They launch
+    the same kernels on the same device state, so token ids must be identical; the sampled mode reports
+    only the launches it bracketed."""
+    b = bundle("nano", 7, wb.WH_PREC_F32, max_batch=8)
+    prompt, eot = small_prompt(b.dims)
+    clips = [ms.synth_clip(40 + i) for i in range(3)]
+    params = wb.DecodeParams(prompt, 24, eot, [eot])
+    b.ctx.profile_enable(False)
+    ref = [t.tolist() for t in b.ctx.transcribe_batch(clips, params)]
+    b.ctx.profile_enable(True)
+    eager = [t.tolist() for t in b.ctx.transcribe_batch(clips, params)]
+    p_all = b.ctx.profile_get()
+    b.ctx.profile_enable(["dec_cross_attn"], stride=4)
+    sampled = [t.tolist() for t in b.ctx.transcribe_batch(clips, params)]
+    p_smp = b.ctx.profile_get()
+    b.ctx.profile_enable(False)
+    assert eager == ref and sampled == ref
+    n_layers = b.dims.dec_layers
+    steps = len(prompt) + 24 - 1                      # decoder positions run (the last token needs no step)
+    assert p_all["dec_cross_attn"]["launches"] == n_layers * steps
+    # prompt positions are always eager; of the remaining graph positions r = 0..R-1 those with r % 4 == 2
+    rem = steps - len(prompt)
+    assert p_smp["dec_cross_attn"]["launches"] == n_layers * (len(prompt) + len([r for r in range(rem) if r % 4 == 2]))
+    assert p_smp.get("dec_self_attn", {"launches": 0})["launches"] == 0 and p_smp["dec_cross_attn"]["ms"] > 0

@@ -275,15 +275,16 @@ class Context:
         self.lib.wh_get_timings(self.h, C.byref(t))
         return {k: getattr(t, k) for k, _ in WhTiming._fields_}
 
-    def profile_enable(self, groups=True):
-        """groups: True/False (all/none) or an iterable of KG_NAMES to event-time."""
+    def profile_enable(self, groups=True, stride: int = 0):
+        """groups: True/False (all/none) or an iterable of KG_NAMES to event-time; stride > 1 samples every
+        stride-th decoder position (the rest replay the hipGraph)."""
         if groups is True:
             mask = (1 << len(KG_NAMES)) - 1
         elif not groups:
             mask = 0
         else:
             mask = sum(1 << KG_NAMES.index(g) for g in groups)
-        self.lib.wh_profile_enable(self.h, mask)
+        self.lib.wh_profile_enable(self.h, mask | ((stride & 0xFFFF) << 16))
 
     def profile_get(self) -> dict:
         ms = (C.c_double * len(KG_NAMES))()

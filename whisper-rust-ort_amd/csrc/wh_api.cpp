@@ -54,9 +54,9 @@ struct Prof {
     int g;
     size_t slot = 0;
     bool on;
-    Prof(wh_ctx* ctx, int group) : c(ctx), g(group), on(ctx->prof && ((ctx->prof_mask >> group) & 1)) {
-        c->prof_launches[g]++;
+    Prof(wh_ctx* ctx, int group) : c(ctx), g(group), on(ctx->prof && !ctx->capturing && ((ctx->prof_mask >> group) & 1)) {
         if (!on) return;
+        c->prof_launches[g]++;  // launches that are bracketed by events
         auto& v = c->prof_events[g];
         if (c->prof_used[g] == v.size()) {
             hipEvent_t a, b;
@@ -366,15 +366,24 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     const int remaining = total_pos - P;
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
-    const bool use_graph = remaining > 1 && !c->prof && !c->no_graph;
+    // with event timing on: every position is launched eagerly (stride 0/1), or only every stride-th one
+    // (sampled live timing) while the others replay the graph
+    const int stride = c->prof ? c->prof_stride : 0;
+    const bool use_graph = remaining > 1 && !c->no_graph && (!c->prof || stride > 1);
     if (use_graph) {
-        CTX_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        launch_step(true);
-        CTX_HIP(c, hipStreamEndCapture(s, &graph));
+        c->capturing = true;   // no event records inside the captured step
+        hipError_t ce = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+        if (ce == hipSuccess) {
+            launch_step(true);
+            ce = hipStreamEndCapture(s, &graph);
+        }
+        c->capturing = false;
+        if (ce != hipSuccess) return fail(c, WH_ERR_HIP, "graph capture of the decode step failed: %s", hipGetErrorString(ce));
         CTX_HIP(c, hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
     }
     for (int r = 0; r < remaining; r++) {
-        if (use_graph) {
+        const bool sampled = c->prof && stride > 1 && (r % stride) == stride / 2;
+        if (use_graph && !sampled) {
             hipError_t ge = hipGraphLaunch(gexec, s);
             if (ge != hipSuccess) {
                 hipGraphExecDestroy(gexec);
@@ -641,8 +650,9 @@ int wh_get_timings(const wh_ctx* c, wh_timing* out) {
 
 int wh_profile_enable(wh_ctx* c, int group_mask) {
     if (!c) return WH_ERR_ARG;
-    c->prof = group_mask != 0;
-    c->prof_mask = group_mask;
+    c->prof = (group_mask & 0xFFFF) != 0;
+    c->prof_mask = group_mask & 0xFFFF;
+    c->prof_stride = (group_mask >> 16) & 0xFFFF;
     return WH_OK;
 }
 int wh_profile_get(const wh_ctx* c, double* ms, int64_t* launches) {

@@ -57,6 +57,8 @@ struct wh_ctx {
     // profiling hooks
     bool prof = false;
     int prof_mask = 0;  // bit g set: kernel group g is bracketed by events
+    int prof_stride = 0;     // > 1: only every stride-th generated position is launched eagerly with events
+    bool capturing = false;  // a decode step is being captured into a hipGraph
     bool no_graph = false;  // WH_NO_GRAPH=1: launch every decode step eagerly
     int prof_group = -1;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[WH_KG_COUNT];
