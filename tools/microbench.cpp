@@ -27,6 +27,8 @@ static double time_chain(hipStream_t s, int reps, const std::function<void()>& l
 
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 64;
+    setvbuf(stdout, nullptr, _IOLBF, 0);
+    if (B < 1 || B > 64) { fprintf(stderr, "B must be 1..64 (buffers are sized for 64 rows)\n"); return 2; }
     const int d = 512, F = 2048, S = 1500, H = 8, V = 51865;
     hipStream_t s; hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
     const int prec = WH_PREC_BF16;
@@ -51,6 +53,12 @@ int main(int argc, char** argv) {
         printf("dec_gemm LN-folded consumer N=1536 : %.2f us\n", time_chain(s, 200, [&]() { wh_launch_dec_gemm(s, prec, false, a); }));
         SkinnyArgs p; p.W = W; p.bias = bias; p.M = B; p.N = d; p.K = d; p.X = X; p.x_mpad = 64; p.R = xres; p.ldr = d; p.C = xres; p.ldc = d; p.xslab_out = C1; p.stats_out = part;
         printf("dec_gemm stats producer N=512 : %.2f us\n", time_chain(s, 200, [&]() { wh_launch_dec_gemm(s, prec, true, p); }));
+        float* cp = (float*)dmalloc((size_t)64 * 32 * d * 4); float* cm = (float*)dmalloc((size_t)64 * 32 * 8 * 2 * 4);
+        p.X = nullptr; p.xpart = cp; p.xml = cm; p.x_heads = 8;
+        for (int sp : {1, 2, 4, 8, 16, 32}) {
+            p.x_splits = sp;
+            printf("dec_gemm stats producer N=512, X merged from %d attention partials : %.2f us\n", p.x_splits, time_chain(s, 200, [&]() { wh_launch_dec_gemm(s, prec, true, p); }));
+        }
     }
     {   // encoder-shaped GEMMs: M = B*1500 rows
         const int M = B * 1500;
@@ -70,16 +78,16 @@ int main(int argc, char** argv) {
     }
     {   // cross attention: distinct K/V planes per "layer" so nothing is cache resident
         const int L = 6; const size_t plane = (size_t)B * S * d;
-        void* kv = dmalloc(plane * 2 * L * 2); void* q = dmalloc((size_t)B * d * 2); void* out = dmalloc((size_t)B * d * 2);
+        void* kv = dmalloc(plane * 2 * L * 2); void* q = dmalloc((size_t)64 * d * 4); void* out = dmalloc((size_t)64 * d * 4);  // slab layouts are padded to 64 rows
         int* tickets = (int*)dmalloc(64 * 4);
-        for (int un : {4, 8}) for (int splits : {1, 2, 4, 8, 16}) {
+        for (int un : {4, 8}) for (int splits : {1, 2, 4, 8, 16, 32}) {
             wh_dbg_cross_unroll = un;
-            float* part = (float*)dmalloc((size_t)B * splits * d * 4); float* ml = (float*)dmalloc((size_t)B * splits * H * 2 * 4);
+            float* part = (float*)dmalloc((size_t)B * 32 * d * 4); float* ml = (float*)dmalloc((size_t)B * 32 * H * 2 * 4);
             int l = 0;
-            double us = time_chain(s, 60, [&]() { wh_launch_dec_cross_attn(s, prec, q, (char*)kv + (size_t)(2 * l) * plane * 2, (char*)kv + (size_t)(2 * l + 1) * plane * 2, part, ml, out, tickets, S, d, H, splits, B, 64); l = (l + 1) % L; });
+            double us = time_chain(s, 60, [&]() { wh_launch_dec_cross_attn(s, prec, q, (char*)kv + (size_t)(2 * l) * plane * 2, (char*)kv + (size_t)(2 * l + 1) * plane * 2, part, ml, S, d, H, splits, B); l = (l + 1) % L; });
             printf("cross_attn B=%d unroll=%d splits=%2d : %.2f us  (%.2f TB/s)\n", B, un, splits, us, 2.0 * S * d * 2 * B / us / 1e6);
         }
-        void* qkv = dmalloc((size_t)B * 3 * d * 2); void* kc = dmalloc((size_t)B * H * 448 * 64 * 2); void* vc = dmalloc((size_t)B * H * 448 * 64 * 2);
+        void* qkv = dmalloc((size_t)64 * 3 * d * 4); void* kc = dmalloc((size_t)B * H * 448 * 64 * 2); void* vc = dmalloc((size_t)B * H * 448 * 64 * 2);
         int hp = 100; hipMemcpy(pos, &hp, 4, hipMemcpyHostToDevice);
         printf("self_attn pos=100 : %.2f us\n", time_chain(s, 100, [&]() { wh_launch_dec_self_attn(s, prec, qkv, kc, vc, out, pos, d, H, 448, B, 64); }));
     }

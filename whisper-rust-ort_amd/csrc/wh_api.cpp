@@ -226,7 +226,6 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     CTX_HIP(c, hipMemsetAsync(c->done, 0, nb * 4, s));
     CTX_HIP(c, hipMemsetAsync(c->pos, 0, 4, s));
     CTX_HIP(c, hipMemsetAsync(c->step_ticket, 0, 4, s));
-    CTX_HIP(c, hipMemsetAsync(c->cross_tickets, 0, nb * 4, s));
     std::vector<int> forced(p->n_forced);
     for (size_t i = 0; i < p->n_forced; i++) forced[i] = (int)p->forced[i];
     if (!forced.empty()) CTX_HIP(c, hipMemcpyAsync(c->forced, forced.data(), forced.size() * 4, hipMemcpyHostToDevice, s));
@@ -316,13 +315,14 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
             {
                 Prof pr(c, WH_KG_DEC_CROSS_ATTN);
                 wh_launch_dec_cross_attn(s, prec, c->dq, (char*)c->cross_kv + (2 * l) * kv_stride * esz,
-                                         (char*)c->cross_kv + (2 * l + 1) * kv_stride * esz, c->cpart, c->cml, c->datt,
-                                         c->cross_tickets, (int)S, (int)d, D.n_heads, c->cross_splits, nb, mpad);
+                                         (char*)c->cross_kv + (2 * l + 1) * kv_stride * esz, c->cpart, c->cml,
+                                         (int)S, (int)d, D.n_heads, c->cross_splits, nb);
             }
-            {   // cross-attention out-proj + residual → x, raw slab, LN3 partials
+            {   // merge of the key ranges ∘ cross-attention out-proj + residual → x, raw slab, LN3 partials
                 Prof pr(c, WH_KG_DEC_GEMM);
                 a = SkinnyArgs();
-                a.X = c->datt; a.x_mpad = mpad; a.W = L.co_w; a.bias = L.co_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
+                a.xpart = c->cpart; a.xml = c->cml; a.x_splits = c->cross_splits; a.x_heads = D.n_heads;
+                a.x_mpad = mpad; a.W = L.co_w; a.bias = L.co_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
                 a.M = nb; a.N = (int)d; a.K = (int)d; a.xslab_out = c->dxs; a.stats_out = c->lnpart;
                 wh_launch_dec_gemm(s, prec, true, a);
             }
@@ -594,7 +594,7 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
     const size_t o_pv = cv.take(B * n_tiles * 4), o_pi = cv.take(B * n_tiles * 4);
     const size_t o_feed = cv.take(B * c->tok_ld * 4), o_out = cv.take(B * c->tok_ld * 4);
     const size_t o_nout = cv.take(B * 4), o_done = cv.take(B * 4), o_forced = cv.take(TC * 4), o_pos = cv.take(4);
-    const size_t o_ctk = cv.take(B * 4), o_stk = cv.take(4);
+    const size_t o_stk = cv.take(4);
     const size_t o_m1 = cv.take((D.vocab / 32 + 1) * 4), o_m2 = cv.take((D.vocab / 32 + 1) * 4);
     const size_t o_ns = cv.take(B * 4), o_nf = cv.take(B * 4), o_si = cv.take(B * 4), o_fs = cv.take(B * 4), o_gm = cv.take(B * 4);
     c->ws_bytes = cv.off;
@@ -611,7 +611,7 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
     c->cpart = (float*)(w + o_cpart); c->cml = (float*)(w + o_cml); c->part_val = (float*)(w + o_pv); c->part_idx = (int*)(w + o_pi);
     c->feed = (int*)(w + o_feed); c->out_tokens = (int*)(w + o_out); c->n_out = (int*)(w + o_nout); c->done = (int*)(w + o_done);
     c->forced = (int*)(w + o_forced); c->pos = (int*)(w + o_pos);
-    c->cross_tickets = (int*)(w + o_ctk); c->step_ticket = (int*)(w + o_stk);
+    c->step_ticket = (int*)(w + o_stk);
     c->mask_first = (unsigned*)(w + o_m1); c->mask_base = (unsigned*)(w + o_m2);
     c->d_nsamp = (int*)(w + o_ns); c->d_nframes = (int*)(w + o_nf); c->d_src_index = (int*)(w + o_si);
     c->d_frame_start = (int*)(w + o_fs); c->d_gmax = (unsigned*)(w + o_gm);

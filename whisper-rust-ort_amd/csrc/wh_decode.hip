@@ -91,7 +91,53 @@ __global__ __launch_bounds__(256) void k_dec_embed(const T* __restrict__ tok_emb
 // to 8 per wave in flight before the first MFMA); activations are read as MFMA column operands from
 // the slab layout.  The waves of a workgroup split K (4 or 8 ways) and reduce through LDS; wave w
 // then finishes row-tile w (bias, erf-GELU, f32 residual; output row-major or slab).
-template <typename T, typename TO, int MT, int NW>
+// Merge of split attention partials (one row, 4 consecutive columns per item), in two phases so that the
+// caller can put every load of several items in flight before any arithmetic.  SP = compile-time bound on
+// the number of key ranges (everything unrolled, selects instead of branches: a branch would end the basic
+// block and serialise the memory round trips).
+template <int SP>
+struct PartRaw {
+    float mv[SP], lv[SP];
+    f32x4 p[SP];
+};
+template <int SP>
+__device__ __forceinline__ void partials_load(const SkinnyArgs& a, int m, int k, PartRaw<SP>& r) {
+    const int h = k / WH_HEAD_DIM, hs = a.x_heads * 2;
+    const float* mb = a.xml + (long)m * a.x_splits * hs + h;
+    const float* pb = a.xpart + (long)m * a.x_splits * a.K + k;
+#pragma unroll
+    for (int s2 = 0; s2 < SP; s2++) {
+        const int sc = s2 < a.x_splits ? s2 : 0;  // clamped re-read, weight forced to 0 in partials_merge
+        r.mv[s2] = mb[sc * hs];
+        r.lv[s2] = mb[sc * hs + a.x_heads];
+        r.p[s2] = *reinterpret_cast<const f32x4*>(pb + (long)sc * a.K);
+    }
+}
+template <int SP>
+__device__ __forceinline__ f32x4 partials_merge(const SkinnyArgs& a, PartRaw<SP>& r, bool live) {
+    float M = -INFINITY;
+#pragma unroll
+    for (int s2 = 0; s2 < SP; s2++) {
+        r.mv[s2] = (s2 < a.x_splits) ? r.mv[s2] : -INFINITY;
+        M = fmaxf(M, r.mv[s2]);
+    }
+    M = (M == -INFINITY) ? 0.0f : M;  // every range empty: exp(-inf - 0) = 0 below, never inf - inf
+    f32x4 acc = {0, 0, 0, 0};
+    float den = 0.0f;
+#pragma unroll
+    for (int s2 = 0; s2 < SP; s2++) {
+        const float w = __builtin_amdgcn_exp2f((r.mv[s2] - M) * 1.44269504088896341f);  // empty key range: m = -inf, weight 0
+        den += w * r.lv[s2];
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[e] += w * r.p[s2][e];
+    }
+    const float inv = live ? __builtin_amdgcn_rcpf(den) : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; e++) acc[e] *= inv;
+    return acc;
+}
+
+template <typename T, typename TO, int MT, int NW, int XP>  // XP > 0: X from XP-bounded attention partials
 __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -102,7 +148,7 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
     if (nrow > a.N - 1) nrow = a.N - 1;
     const int kspan = a.K / NW, kb = wave * kspan, iters = kspan >> 5;
     const T* wp = (const T*)a.W + (long)nrow * a.K + kb + fg * 8;
-    const T* xp = (const T*)a.X + ((long)(kb >> 5) * a.x_mpad + m0 + fl) * 32 + fg * 8;
+    const T* xp = XP > 0 ? nullptr : (const T*)a.X + ((long)(kb >> 5) * a.x_mpad + m0 + fl) * 32 + fg * 8;
     const long xstep = (long)a.x_mpad * 32;
     constexpr int DEPTH = 8;
     typename FragT<T>::type wq[DEPTH], xq[DEPTH][MT];
@@ -110,8 +156,10 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
     for (int i = 0; i < DEPTH; i++)
         if (i < iters) {
             wq[i] = load_frag<T>(wp + i * 32);
+            if constexpr (XP == 0) {
 #pragma unroll
-            for (int t = 0; t < MT; t++) xq[i][t] = load_frag<T>(xp + i * xstep + t * 512);
+                for (int t = 0; t < MT; t++) xq[i][t] = load_frag<T>(xp + i * xstep + t * 512);
+            }
         }
     // epilogue operands (wave w finishes row-tile w): fetched now, used last
     f32x4 pre_bias = {0, 0, 0, 0}, pre_r = {0, 0, 0, 0};
@@ -152,6 +200,42 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
     f32x4 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; t++) acc[t] = f32x4{0, 0, 0, 0};
+    if constexpr (XP > 0) {
+        // X = merge of the key ranges' partials, built once per workgroup in LDS (slab layout [K/32][16][32]) with
+        // row-contiguous 16-byte loads; the weight fragments above are in flight meanwhile (iters <= DEPTH here)
+        static_assert(MT == 1, "merged-X variant runs 16-row groups");
+        T* Xs = reinterpret_cast<T*>(smem_raw + (size_t)NW * 64 * 16 + 4 * 16 * 2 * 4);
+        constexpr int NT = NW * 64, IF = XP <= 4 ? 4 : (XP <= 8 ? 2 : 1);    // items in flight per thread
+        // 4-column chunks per row; only live rows are merged (a dead row of X feeds only its own, never stored,
+        // output column of the MFMA tile)
+        const int cpr = a.K >> 2, items = min(16, a.M - m0) * cpr;
+        for (int it0 = tid; it0 < items; it0 += NT * IF) {
+            PartRaw<XP> raw[IF];
+            int row[IF], ch[IF];
+            bool live[IF];
+#pragma unroll
+            for (int u = 0; u < IF; u++) {
+                const int item = min(it0 + u * NT, items - 1);
+                row[u] = item / cpr;
+                ch[u] = item - row[u] * cpr;
+                live[u] = it0 + u * NT < items;
+                partials_load<XP>(a, m0 + row[u], ch[u] * 4, raw[u]);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // all loads above, all arithmetic below
+#pragma unroll
+            for (int u = 0; u < IF; u++) {
+                const f32x4 v = partials_merge<XP>(a, raw[u], live[u]);
+                const int k = ch[u] * 4;
+                if (live[u]) store4(Xs + ((long)(k >> 5) * 16 + row[u]) * 32 + (k & 31), v[0], v[1], v[2], v[3]);
+            }
+        }
+        __syncthreads();
+        const T* xl = Xs + ((long)(kb >> 5) * 16 + fl) * 32 + fg * 8;
+#pragma unroll
+        for (int i = 0; i < DEPTH; i++)
+            if (i < iters) mma16(acc[0], wq[i], load_frag<T>(xl + i * 512));
+        for (int i = DEPTH; i < iters; i++) mma16(acc[0], load_frag<T>(wp + i * 32), load_frag<T>(xl + i * 512));  // deep K tail
+    } else
     for (int c0 = 0; c0 < iters; c0 += DEPTH) {
         if (c0 > 0) {
 #pragma unroll
@@ -406,7 +490,6 @@ __global__ __launch_bounds__(64) void k_dec_self_attn(const T* __restrict__ qkv,
     constexpr int HD = WH_HEAD_DIM;
     constexpr int EPC = 16 / (int)sizeof(T);
     typedef typename FragT<T>::type frag_t;
-    typedef __attribute__((ext_vector_type(EPC))) T vec_t;
     __shared__ __attribute__((aligned(16))) float qs[HD];
     __shared__ __attribute__((aligned(16))) float sc[512];
     const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x, pos = *pos_p;
@@ -492,9 +575,8 @@ __global__ __launch_bounds__(64) void k_dec_self_attn(const T* __restrict__ qkv,
 template <typename T, int NCH, int UNROLL>  // NCH = ceil(d*sizeof(T)/16 / 64): 16-B chunks per lane per row
 __global__ __launch_bounds__(256) void k_dec_cross_attn(const T* __restrict__ q, const T* __restrict__ ck,
                                                         const T* __restrict__ cv, float* __restrict__ part,
-                                                        float* __restrict__ ml, T* __restrict__ out,
-                                                        int* __restrict__ tickets, int S, int d, int n_heads,
-                                                        int splits, int mpad) {
+                                                        float* __restrict__ ml, int S, int d, int n_heads,
+                                                        int splits) {
     constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-B chunk: 8 (bf16) / 4 (f32)
     constexpr int LPH = WH_HEAD_DIM / EPC;     // lanes per head: 8 / 16
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -628,8 +710,9 @@ __global__ __launch_bounds__(256) void k_dec_cross_attn(const T* __restrict__ q,
         }
     }
     __syncthreads();
-    // Publish this key range's partial WRITE-THROUGH (sc1 stores: no L2 write-back fence needed),
-    // drain, arrive on the clip's ticket; the last range to arrive merges all ranges.
+    // this key range's partial (unnormalised output, running max, running sum); the consumer GEMM merges
+    // the ranges of a clip while it builds its MFMA operand (frag_from_partials), so nothing is exchanged
+    // between workgroups here and the kernel ends with its last store
     float* pp = part + ((long)b * splits + sp) * d;
     float* mp = ml + ((long)b * splits + sp) * n_heads * 2;
     for (int n = tid; n < d; n += 256) {
@@ -643,53 +726,11 @@ __global__ __launch_bounds__(256) void k_dec_cross_attn(const T* __restrict__ q,
             num += sc * wo[w * d + n];
             den += sc * wl[w * n_heads + h];
         }
-        __hip_atomic_store(pp + n, num, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pp[n] = num;
         if ((n % WH_HEAD_DIM) == 0) {
-            __hip_atomic_store(mp + h, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(mp + n_heads + h, den, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mp[h] = M;
+            mp[n_heads + h] = den;
         }
-    }
-    __shared__ int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
-    __syncthreads();
-    if (tid == 0) {
-        const int t = __hip_atomic_fetch_add(tickets + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == splits - 1);
-        if (s_last) {
-            __hip_atomic_store(tickets + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // merge: every partial of this clip is loaded (L1-bypassing, all loads in flight) before use
-    constexpr int MAXS = 32;
-    const float* pb = part + (long)b * splits * d;
-    const float* mb = ml + (long)b * splits * n_heads * 2;
-    for (int n = tid; n < d; n += 256) {
-        const int h = n / WH_HEAD_DIM;
-        float mv[MAXS], lv[MAXS], pv[MAXS];
-#pragma unroll
-        for (int s2 = 0; s2 < MAXS; s2++) {
-            mv[s2] = -INFINITY; lv[s2] = 0.0f; pv[s2] = 0.0f;
-            if (s2 < splits) {
-                mv[s2] = __hip_atomic_load(mb + s2 * n_heads * 2 + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                lv[s2] = __hip_atomic_load(mb + s2 * n_heads * 2 + n_heads + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pv[s2] = __hip_atomic_load(pb + (long)s2 * d + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        float M = -INFINITY;
-#pragma unroll
-        for (int s2 = 0; s2 < MAXS; s2++) M = fmaxf(M, mv[s2]);
-        float num = 0.0f, den = 0.0f;
-#pragma unroll
-        for (int s2 = 0; s2 < MAXS; s2++) {
-            const float w = (mv[s2] == -INFINITY) ? 0.0f : __expf(mv[s2] - M);
-            num += w * pv[s2];
-            den += w * lv[s2];
-        }
-        out[slab_idx(b, n, mpad)] = cvt_out<T>(num / den);
     }
 }
 
@@ -719,11 +760,20 @@ void launch_dec_gemm_mt(hipStream_t s, const SkinnyArgs& a) {
     const int mt = std::min(mt_cap, (a.M + 15) / 16);
     const size_t sm = (size_t)NW * mt * 64 * 16 + (size_t)4 * mt * 16 * 2 * 4;
     dim3 grid(n_tiles, (a.M + 16 * mt - 1) / (16 * mt));
+    if (a.xpart) {  // X merged from attention partials: 16-row groups only (the merge is per-lane work)
+        dim3 g1(n_tiles, (a.M + 15) / 16);
+        const size_t sm1 = (size_t)NW * 64 * 16 + 4 * 16 * 2 * 4 + (size_t)16 * a.K * sizeof(T);  // + merged X tile
+        if (a.x_splits <= 4) { set_max_smem(k_dec_gemm<T, TO, 1, NW, 4>, sm1); hipLaunchKernelGGL((k_dec_gemm<T, TO, 1, NW, 4>), g1, dim3(NW * 64), sm1, s, a); }
+        else if (a.x_splits <= 8) { set_max_smem(k_dec_gemm<T, TO, 1, NW, 8>, sm1); hipLaunchKernelGGL((k_dec_gemm<T, TO, 1, NW, 8>), g1, dim3(NW * 64), sm1, s, a); }
+        else if (a.x_splits <= 16) { set_max_smem(k_dec_gemm<T, TO, 1, NW, 16>, sm1); hipLaunchKernelGGL((k_dec_gemm<T, TO, 1, NW, 16>), g1, dim3(NW * 64), sm1, s, a); }
+        else { set_max_smem(k_dec_gemm<T, TO, 1, NW, 32>, sm1); hipLaunchKernelGGL((k_dec_gemm<T, TO, 1, NW, 32>), g1, dim3(NW * 64), sm1, s, a); }
+        return;
+    }
     switch (mt) {
-        case 1: hipLaunchKernelGGL((k_dec_gemm<T, TO, 1, NW>), grid, dim3(NW * 64), sm, s, a); break;
-        case 2: hipLaunchKernelGGL((k_dec_gemm<T, TO, 2, NW>), grid, dim3(NW * 64), sm, s, a); break;
-        case 3: hipLaunchKernelGGL((k_dec_gemm<T, TO, 3, NW>), grid, dim3(NW * 64), sm, s, a); break;
-        default: hipLaunchKernelGGL((k_dec_gemm<T, TO, 4, NW>), grid, dim3(NW * 64), sm, s, a); break;
+        case 1: hipLaunchKernelGGL((k_dec_gemm<T, TO, 1, NW, 0>), grid, dim3(NW * 64), sm, s, a); break;
+        case 2: hipLaunchKernelGGL((k_dec_gemm<T, TO, 2, NW, 0>), grid, dim3(NW * 64), sm, s, a); break;
+        case 3: hipLaunchKernelGGL((k_dec_gemm<T, TO, 3, NW, 0>), grid, dim3(NW * 64), sm, s, a); break;
+        default: hipLaunchKernelGGL((k_dec_gemm<T, TO, 4, NW, 0>), grid, dim3(NW * 64), sm, s, a); break;
     }
 }
 
@@ -731,7 +781,8 @@ template <typename T, typename TO>
 void launch_dec_gemm_split(hipStream_t s, const SkinnyArgs& a) {
     // K is split over the waves of a workgroup: 8 ways when it is deep, else 4 (K % 128 == 0 always
     // holds: d_model and ffn are multiples of 128, checked at model load)
-    if (a.K >= 2048 && a.K % 256 == 0) launch_dec_gemm_mt<T, TO, 8>(s, a);
+    // (X from attention partials: 8 ways too — fewer fragments to merge per lane)
+    if ((a.K >= 2048 || a.xpart) && a.K % 256 == 0) launch_dec_gemm_mt<T, TO, 8>(s, a);
     else launch_dec_gemm_mt<T, TO, 4>(s, a);
 }
 
@@ -797,11 +848,11 @@ void wh_launch_dec_self_attn(hipStream_t s, int prec, const void* qkv, void* kc,
 }
 
 void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void* ck, const void* cv, float* part,
-                              float* ml, void* out, int* tickets, int S, int d, int n_heads, int splits, int B, int mpad) {
+                              float* ml, int S, int d, int n_heads, int splits, int B) {
     dim3 grid(splits, B);
     const size_t sm = sizeof(float) * ((size_t)8 * n_heads + 4 * (size_t)d);
 #define WH_CA(T_, N_, U_) hipLaunchKernelGGL((k_dec_cross_attn<T_, N_, U_>), grid, dim3(256), sm, s, (const T_*)q, (const T_*)ck, \
-                                             (const T_*)cv, part, ml, (T_*)out, tickets, S, d, n_heads, splits, mpad)
+                                             (const T_*)cv, part, ml, S, d, n_heads, splits)
     if (prec == WH_PREC_F32) {
         const int nch = (d / 4 + 63) / 64;  // f32: 4 elements per chunk
         if (nch == 1) WH_CA(float, 1, 4);

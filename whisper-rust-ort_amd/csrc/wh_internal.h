@@ -110,7 +110,7 @@ struct wh_ctx {
     float* part_val = nullptr;  // [B][n_tiles]
     int* part_idx = nullptr;
     int *feed = nullptr, *out_tokens = nullptr, *n_out = nullptr, *done = nullptr, *forced = nullptr, *pos = nullptr;
-    int *cross_tickets = nullptr, *step_ticket = nullptr;  // zeroed at creation, re-armed by their last arriver
+    int* step_ticket = nullptr;  // zeroed at creation, re-armed by its last arriver
     unsigned *mask_first = nullptr, *mask_base = nullptr;
     float* logits = nullptr;    // optional parity buffer (grown on demand)
     size_t logits_cap = 0;

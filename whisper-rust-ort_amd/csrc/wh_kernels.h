@@ -39,6 +39,12 @@ struct SkinnyArgs {
     const float* ln_part = nullptr;
     int ln_tiles = 0;
     const float* ln_s = nullptr;
+    // X given as split cross-attention partials instead of a slab (X == nullptr): row m, column k is
+    //   sum_s w_s * xpart[m][s][k] / sum_s w_s * l_s,  w_s = exp(m_s - max_s m_s),  {m_s, l_s} = xml[m][s][head(k)][0..1]
+    // (the merge of the key ranges happens in the consumer: no cross-workgroup exchange inside the attention kernel)
+    const float* xpart = nullptr;  // [M][x_splits][K] unnormalised partial outputs
+    const float* xml = nullptr;    // [M][x_splits][x_heads][2]
+    int x_splits = 0, x_heads = 0;
     // producer of the next LayerNorm's input: besides C (f32 row-major residual stream) also write the
     // raw rows in the compute dtype, slab layout, and this column tile's partial sums
     void* xslab_out = nullptr;   // [N/32][x_mpad][32]
@@ -95,7 +101,7 @@ void wh_launch_argmax_finish(hipStream_t s, const float* part_val, const int* pa
 void wh_launch_dec_self_attn(hipStream_t s, int prec, const void* qkv, void* kc, void* vc, void* out, const int* pos_p,
                              int d, int n_heads, int tc, int B, int mpad);
 void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void* ck, const void* cv, float* part,
-                              float* ml, void* out, int* tickets, int S, int d, int n_heads, int splits, int B, int mpad);
+                              float* ml, int S, int d, int n_heads, int splits, int B);
 
 extern int wh_dbg_cross_unroll;
 extern int wh_dbg_lm_blocks_per_cu;
