@@ -65,7 +65,7 @@ class Hip:
         self.check(self.lib.hipDeviceSynchronize(), "hipDeviceSynchronize")
 
 
-def algorithmic_work(dims, n_clips: int, n_prompt: int, max_new: int, esz: int) -> dict:
+def algorithmic_work(dims, n_clips: int, n_prompt: int, max_new: int, kv_esz: int) -> dict:
     """SURVEY.md §8d formulas, per launch / per batch."""
     d, F, T, Ld, Le, V, M = dims.d_model, dims.ffn, dims.n_audio_ctx, dims.dec_layers, dims.enc_layers, dims.vocab, dims.n_mels
     enc_flop = 2 * d * M * 3 * 3000 + 2 * d * d * 3 * T + Le * (2 * 4 * T * d * d + 2 * 2 * T * T * d + 2 * 2 * T * d * F)
@@ -78,7 +78,7 @@ def algorithmic_work(dims, n_clips: int, n_prompt: int, max_new: int, esz: int) 
         "cross_kv_flop_per_clip": cross_kv_flop,
         "dec_flop_per_clip": dec_flop,
         # one cross-attention launch reads K and V of one layer for every clip of the batch, once
-        "cross_attn_bytes_per_launch": 2 * T * d * esz * n_clips,
+        "cross_attn_bytes_per_launch": 2 * T * d * kv_esz * n_clips,   # kv_esz: 4 f32, 2 bf16, 1 e4m3
         "cross_attn_launches": positions * Ld,
         "mel_bytes_per_clip": 480000 * 4 + M * 3000 * 4,
     }
@@ -112,7 +112,7 @@ def main() -> None:
     ap.add_argument("--clips", type=int, default=64, help="clips per GPU per step (batch resident in HBM)")
     ap.add_argument("--streams", type=int, default=1, help="independent HIP streams (contexts) per GPU; clips are split evenly")
     ap.add_argument("--preset", default="base")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "fp8"])
     ap.add_argument("--max-new-tokens", type=int, default=128)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -156,8 +156,8 @@ def main() -> None:
                 backend = "gloo"
 
     dims = ms.PRESETS[a.preset]
-    prec = wb.WH_PREC_BF16 if a.precision == "bf16" else wb.WH_PREC_F32
-    esz = 2 if prec == wb.WH_PREC_BF16 else 4
+    prec = wb.PRECISIONS[a.precision]
+    esz = 4 if prec == wb.WH_PREC_F32 else 2
     if wb.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: libwhisper_hip has no CPU fallback")
     dev = local_rank
@@ -256,7 +256,7 @@ def main() -> None:
         n_results = len(toks)
 
     if rank == 0:
-        work = algorithmic_work(dims, per_stream, len(prompt), a.max_new_tokens, esz)
+        work = algorithmic_work(dims, per_stream, len(prompt), a.max_new_tokens, 1 if prec == wb.WH_PREC_FP8 else esz)
         audio_s = 30.0 * a.clips * a.steps * world
         ms_per_step = elapsed / a.steps * 1e3
         # Roofline of the dominant kernel (k_dec_cross_attn: largest single-kernel share in every
@@ -273,9 +273,9 @@ def main() -> None:
         if os.path.exists(tpath):   # HBM bytes per launch from rocprofv3 --pmc passes (see profiles/README.md)
             tj = json.load(open(tpath))
             key = f"{a.preset}_{a.precision}_b{per_stream}"
-            traffic = tj.get("k_dec_cross_attn", {}).get(key)
+            traffic = tj.get("k_dec_cross_attn8" if prec == wb.WH_PREC_FP8 else "k_dec_cross_attn", {}).get(key)
         roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": traffic, "kernel": "k_dec_cross_attn", "avg_launch_us": avg_s * 1e6,
+                    "traffic": traffic, "kernel": "k_dec_cross_attn8" if prec == wb.WH_PREC_FP8 else "k_dec_cross_attn", "avg_launch_us": avg_s * 1e6,
                     "launches_timed": live["launches"], "alg_bytes_per_launch": work["cross_attn_bytes_per_launch"],
                     "share_of_kernel_time": breakdown["dec_cross_attn"]["ms"] / tot_ms}
         out = {

@@ -50,6 +50,11 @@ extern "C" {
 /* arithmetic type of the Linear/conv/attention contractions */
 #define WH_PREC_F32 0  /* exact-f32 MFMA (v_mfma_f32_16x16x4_f32): the token-for-token / 1e-3-logit mode */
 #define WH_PREC_BF16 1 /* bf16 MFMA, f32 accumulate, f32 residual stream: the throughput mode */
+#define WH_PREC_FP8 2  /* BASELINE configs[4]: Linear/QKV weights as OCP e4m3 codes with one f32 scale per output channel
+                          (dequantised in registers, bf16 MFMA, f32 accumulate and scale), cross-attention K/V cache as
+                          e4m3 with one scale per (clip, layer, K|V, head); convolutions, LayerNorms, biases, embeddings
+                          and all activations as in WH_PREC_BF16.  Reference analogue: weights-only QInt8 on
+                          MatMul/Gemm, quantize_onnx_int8.py:37-42 */
 
 #define WH_N_FRAMES 3000      /* mel frames per 30 s window (src/main.rs:896) */
 #define WH_CLIP_SAMPLES 480000 /* 30 s @ 16 kHz */
@@ -176,6 +181,10 @@ int wh_profile_get(const wh_ctx* c, double* ms /* [WH_KG_COUNT] */, int64_t* lau
  * tensor order (needs no device).  out == NULL → only *n_out is written. */
 int wh_synthetic_weights(const char* preset, uint64_t seed, float* out, size_t cap, size_t* n_out);
 
+/* OCP e4m3fn codes as WH_PREC_FP8 stores them (round to nearest even, saturating at +-448): host-side helpers for
+ * the offline weight conversion (reference analogue: quantize_onnx_int8.py:31-42) and for tests. */
+void wh_e4m3_quantize(const float* x, size_t n, uint8_t* codes);
+void wh_e4m3_dequantize(const uint8_t* codes, size_t n, float* x);
 int wh_abi_version(void);
 int wh_device_count(void);
 

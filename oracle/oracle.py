@@ -73,6 +73,10 @@ def lib() -> C.CDLL:
         L.orc_decode_greedy.argtypes = [C.POINTER(OrcDims), f32p, f32p, i64p, C.c_size_t, C.c_size_t,
                                         C.c_int64, i64p, C.c_size_t, i64p, C.c_size_t, i64p, C.c_size_t,
                                         i64p, C.POINTER(C.c_size_t), f32p]
+        u8p = C.POINTER(C.c_uint8)
+        L.orc_e4m3_quantize.argtypes = [f32p, C.c_size_t, u8p]
+        L.orc_e4m3_dequantize.argtypes = [u8p, C.c_size_t, f32p]
+        L.orc_set_kv_fp8.argtypes = [C.c_int]
         L.orc_num_threads.restype = C.c_int
         L.orc_set_threads.argtypes = [C.c_int]
         L.orc_set_threads(int(os.environ["OMP_NUM_THREADS"]))
@@ -147,8 +151,9 @@ def argmax_last_row(logits: np.ndarray, suppress: Sequence[int] = ()) -> int:
 
 def decode_greedy(dims, wflat: np.ndarray, enc: np.ndarray, prompt: Sequence[int], max_new: int, eot: int,
                   suppress: Sequence[int] = (), begin_suppress: Sequence[int] = (),
-                  forced: Optional[Sequence[int]] = None, want_logits: bool = False
+                  forced: Optional[Sequence[int]] = None, want_logits: bool = False, kv_fp8: bool = False
                   ) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+    """kv_fp8: cross-attention K/V pass through e4m3 with one scale per (layer, K|V, head) — the build's fp8 mode."""
     enc = np.ascontiguousarray(enc, np.float32)
     pr = np.asarray(list(prompt), np.int64)
     sup = np.asarray(list(suppress), np.int64)
@@ -157,14 +162,32 @@ def decode_greedy(dims, wflat: np.ndarray, enc: np.ndarray, prompt: Sequence[int
     toks = np.zeros(pr.size + max_new, np.int64)
     n_out = C.c_size_t(0)
     logits = np.zeros((max_new, dims.vocab), np.float32) if want_logits else None
-    rc = lib().orc_decode_greedy(C.byref(dims_struct(dims)), _f32(wflat), _f32(enc), _i64(pr), pr.size, max_new,
-                                 eot, _i64(sup), sup.size, _i64(bsup), bsup.size,
-                                 _i64(fo) if fo.size else None, fo.size, _i64(toks), C.byref(n_out),
-                                 _f32(logits) if want_logits else None)
+    lib().orc_set_kv_fp8(1 if kv_fp8 else 0)
+    try:
+        rc = lib().orc_decode_greedy(C.byref(dims_struct(dims)), _f32(wflat), _f32(enc), _i64(pr), pr.size, max_new,
+                                     eot, _i64(sup), sup.size, _i64(bsup), bsup.size,
+                                     _i64(fo) if fo.size else None, fo.size, _i64(toks), C.byref(n_out),
+                                     _f32(logits) if want_logits else None)
+    finally:
+        lib().orc_set_kv_fp8(0)
     if rc:
         raise RuntimeError(f"orc_decode_greedy rc={rc}")
     n = int(n_out.value)
     return toks[:n].copy(), (logits[: n - pr.size].copy() if want_logits else None)
+
+
+def e4m3_quantize(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros(x.shape, np.uint8)
+    lib().orc_e4m3_quantize(_f32(x), x.size, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
+def e4m3_dequantize(c: np.ndarray) -> np.ndarray:
+    c = np.ascontiguousarray(c, np.uint8)
+    out = np.zeros(c.shape, np.float32)
+    lib().orc_e4m3_dequantize(c.ctypes.data_as(C.POINTER(C.c_uint8)), c.size, _f32(out))
+    return out
 
 
 def num_threads() -> int:

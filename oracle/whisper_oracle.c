@@ -579,6 +579,56 @@ static void dec_position(dec_state* st, int64_t token, size_t pos, float* logits
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * fp8 (OCP e4m3fn) restatement for the build's fp8 mode.  The reference's analogue is
+ * weights-only QInt8 on MatMul/Gemm (quantize_onnx_int8.py:37-42); e4m3 itself is the published OCP 8-bit
+ * format: 1-4-3, bias 7, max 448, no infinities, S.1111.111 = NaN.  Round to nearest even, saturating.
+ * Twins: modelspec.quantize_e4m3 (numpy), wh_quantize_e4m3 (csrc/wh_model.cpp).
+ * ---------------------------------------------------------------------------------------- */
+static uint8_t e4m3_from_f32(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const uint8_t sign = (uint8_t)((u >> 24) & 0x80);
+    if (x != x) return 0x7F;
+    float a = fabsf(x);
+    if (a > 448.0f) a = 448.0f;
+    if (a >= 0.015625f) { /* normal: RNE at mantissa bit 20 */
+        memcpy(&u, &a, 4);
+        u += 0x7FFFFu + ((u >> 20) & 1u);
+        uint32_t code = (((u >> 23) - 120u) << 3) | ((u >> 20) & 7u);
+        if (code > 0x7Eu) code = 0x7Eu;
+        return (uint8_t)(code | sign);
+    }
+    return (uint8_t)((uint32_t)nearbyint((double)a * 512.0) | sign); /* multiples of 2^-9; 8 = first normal */
+}
+static float e4m3_to_f32(uint8_t c) {
+    const int e = (c >> 3) & 15, m = c & 7;
+    float mag = e == 0 ? (float)m * 0.001953125f : ldexpf((float)(8 + m), e - 10);
+    if ((c & 0x7F) == 0x7F) mag = NAN;
+    return (c & 0x80) ? -mag : mag;
+}
+void orc_e4m3_quantize(const float* x, size_t n, uint8_t* out) { for (size_t i = 0; i < n; i++) out[i] = e4m3_from_f32(x[i]); }
+void orc_e4m3_dequantize(const uint8_t* c, size_t n, float* out) { for (size_t i = 0; i < n; i++) out[i] = e4m3_to_f32(c[i]); }
+
+/* fp8 cross-attention K/V cache: one scale per (layer, K|V, head) = max|.| / 448 over the clip's 1500 x 64
+ * block, values stored as e4m3 codes of value / scale — restated as quantise-dequantise in place. */
+static int g_kv_fp8 = 0;
+void orc_set_kv_fp8(int on) { g_kv_fp8 = on; }
+static void fake_quant_heads(float* kv /* [T][d] */, size_t T, size_t d, size_t n_heads) {
+    const size_t hd = d / n_heads;
+    for (size_t h = 0; h < n_heads; h++) {
+        float amax = 0.0f;
+        for (size_t t = 0; t < T; t++)
+            for (size_t e = 0; e < hd; e++) amax = fmaxf(amax, fabsf(kv[t * d + h * hd + e]));
+        const float scale = amax > 0.0f ? amax / 448.0f : 1.0f;
+        for (size_t t = 0; t < T; t++)
+            for (size_t e = 0; e < hd; e++) {
+                float* v = &kv[t * d + h * hd + e];
+                *v = e4m3_to_f32(e4m3_from_f32(*v / scale)) * scale;
+            }
+    }
+}
+
 int orc_decode_greedy(const orc_dims* c, const float* w, const float* enc /* [T][d] */,
                       const int64_t* prompt, size_t p, size_t max_new, int64_t eot,
                       const int64_t* suppress, size_t ns, const int64_t* begin_suppress, size_t nb,
@@ -606,6 +656,10 @@ int orc_decode_greedy(const orc_dims* c, const float* w, const float* enc /* [T]
     for (size_t li = 0; li < Ld; li++) {
         gemm_nt(enc, d, st.m.dec[li].ca.kw, NULL, st.crossk + li * T * d, d, T, d, d);
         gemm_nt(enc, d, st.m.dec[li].ca.vw, st.m.dec[li].ca.vb, st.crossv + li * T * d, d, T, d, d);
+        if (g_kv_fp8) {
+            fake_quant_heads(st.crossk + li * T * d, T, d, (size_t)c->n_heads);
+            fake_quant_heads(st.crossv + li * T * d, T, d, (size_t)c->n_heads);
+        }
     }
     /* suppress sets, :765-768 */
     int64_t* sup_first = (int64_t*)malloc(sizeof(int64_t) * (ns + nb + 1));

@@ -1,0 +1,82 @@
+"""WH_PREC_FP8 (BASELINE configs[4]: e4m3 Linear/QKV weights + e4m3 cross-attention K/V cache) against the oracle
+run on the SAME quantised model: weights through modelspec.fake_quant_state_dict (dequant(quant(W)), bit-identical
+to the library's own quantiser — tests/test_fp8_cpu.py), cross K/V through the oracle's kv_fp8 switch.  What is
+left between the two is bf16 activations vs f32, so the bounds are those of the bf16 mode."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from whisper_rust_ort_amd import binding as wb
+from whisper_rust_ort_amd import modelspec as ms
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if wb.device_count() < 1:
+        pytest.fail("no MI355X visible: the GPU suite has no fallback")
+    return 0
+
+
+def small_prompt(dims):
+    return ([50258, 50259, 50359, 50363], 50257) if dims.vocab > 50400 else ([3, 5, 7, 9], 2)
+
+
+@pytest.mark.parametrize("preset,seed,clip,n_new", [("nano", 7, 0, 24), ("micro", 11, 2, 16)])
+def test_fp8_teacher_forced_vs_quantised_oracle(gpu, preset, seed, clip, n_new):
+    dims = ms.PRESETS[preset]
+    sd = ms.synth_state_dict(dims, seed)
+    wq = ms.flatten_state_dict(dims, ms.fake_quant_state_dict(sd))
+    pcm = ms.synth_clip(clip)
+    prompt, eot = small_prompt(dims)
+    mel = orc.window_mel(orc.log_mel(pcm, dims.n_mels), 0, 3000)
+    enc_o = orc.encoder(dims, wq, mel)
+    tok_o, log_o = orc.decode_greedy(dims, wq, enc_o, prompt, n_new, eot, suppress=[eot], want_logits=True, kv_fp8=True)
+    gen = tok_o[len(prompt):].tolist()
+
+    model = wb.Model(f"synthetic:{preset}:{seed}", 0, wb.WH_PREC_FP8)
+    assert model.lib.wh_model_precision(model.h) == wb.WH_PREC_FP8
+    ctx = wb.Context(model, 1)
+    enc = ctx.run_encoder(ctx.whisper_log_mel(pcm))
+    enc_err = np.abs(enc - enc_o).max()
+    assert enc_err < 0.08, enc_err
+    tc, lc = ctx.greedy_decode_with_past(wb.DecodeParams(prompt, n_new, eot, [eot], forced=gen[:-1]), want_logits=True)
+    assert len(lc) == len(log_o)
+    errs = [np.abs(lc[i] - log_o[i]).max() for i in range(len(lc))]
+    bound = 2.0 * max(errs)
+    decided = agree = 0
+    for i in range(len(lc)):
+        top2 = np.partition(log_o[i], -2)[-2:]
+        if top2[1] - top2[0] > bound:
+            decided += 1
+            agree += int(tc[len(prompt) + i] == gen[i])
+    print(f"{preset}: fp8 vs quantised oracle: encoder err {enc_err:.4f}, max logit err {max(errs):.4f}, "
+          f"mean {np.mean(errs):.4f}; decided {decided}/{len(lc)} agree {agree}")
+    assert max(errs) < 0.25
+    assert agree == decided
+
+    # the quantisation itself moves the logits by far more than the bf16 arithmetic does: the fp8 run must sit
+    # closer to the quantised oracle than to the unquantised one (i.e. the codes and scales really are in use)
+    w0 = ms.flatten_state_dict(dims, sd)
+    enc_0 = orc.encoder(dims, w0, mel)
+    _, log_0 = orc.decode_greedy(dims, w0, enc_0, prompt, n_new, eot, suppress=[eot], forced=gen[:-1], want_logits=True)
+    d_q = np.mean([np.abs(lc[i] - log_o[i]).mean() for i in range(len(lc))])
+    d_0 = np.mean([np.abs(lc[i] - log_0[i]).mean() for i in range(len(lc))])
+    print(f"{preset}: mean |logit diff| to quantised oracle {d_q:.5f}, to f32 oracle {d_0:.5f}")
+    assert d_q < d_0
+
+
+def test_fp8_batch_matches_single_and_is_deterministic(gpu):
+    dims = ms.PRESETS["micro"]
+    model = wb.Model("synthetic:micro:11", 0, wb.WH_PREC_FP8)
+    ctx = wb.Context(model, 8)
+    prompt, eot = small_prompt(dims)
+    clips = [ms.synth_clip(70 + i)[: 480000 - 40000 * i] for i in range(6)]  # ragged lengths
+    params = wb.DecodeParams(prompt, 20, eot, [eot])
+    a = ctx.transcribe_batch(clips, params)
+    b = ctx.transcribe_batch(clips, params)
+    assert [t.tolist() for t in a] == [t.tolist() for t in b]
+    for i in (0, 3, 5):   # clips are independent units: each head's K/V scale is per clip
+        assert ctx.transcribe_batch([clips[i]], params)[0].tolist() == a[i].tolist()
+    assert all(len(t) == len(prompt) + 20 for t in a)

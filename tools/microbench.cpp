@@ -47,6 +47,12 @@ int main(int argc, char** argv) {
         }
         wh_dbg_mt = 0;
     }
+    for (auto nk : std::vector<std::pair<int, int>>{{512, 512}, {1536, 512}, {2048, 512}, {512, 2048}}) {   // e4m3 weight codes
+        SkinnyArgs a; a.W = W; a.bias = bias; a.wscale = bias; a.M = B; a.N = nk.first; a.K = nk.second; a.X = X; a.x_mpad = 64;
+        const bool res = nk.first == d;
+        if (res) { a.R = xres; a.ldr = d; a.C = xres; a.ldc = d; } else { a.C = C1; a.c_mpad = 64; }
+        printf("dec_gemm fp8 weights M=%d N=%4d K=%4d : %.2f us\n", B, nk.first, nk.second, time_chain(s, 200, [&]() { wh_launch_dec_gemm(s, WH_PREC_FP8, res, a); }));
+    }
     {   // LN-folded consumer + stats-producing residual GEMM
         float* part = (float*)dmalloc(32 * 64 * 2 * 4); float* sv = (float*)dmalloc(F * 4);
         SkinnyArgs a; a.W = W; a.bias = bias; a.M = B; a.N = 3 * d; a.K = d; a.X = X; a.x_mpad = 64; a.C = C1; a.ldc = 3 * d; a.ln_part = part; a.ln_tiles = 32; a.ln_s = sv;

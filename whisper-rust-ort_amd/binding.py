@@ -20,7 +20,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libwhisper_hip.so")
 
-WH_PREC_F32, WH_PREC_BF16 = 0, 1
+WH_PREC_F32, WH_PREC_BF16, WH_PREC_FP8 = 0, 1, 2
+PRECISIONS = {"f32": WH_PREC_F32, "bf16": WH_PREC_BF16, "fp8": WH_PREC_FP8}
 WH_N_FRAMES, WH_CLIP_SAMPLES = 3000, 480000
 KG_NAMES = ("mel", "enc_gemm", "enc_attn", "dec_cross_attn", "dec_gemm", "dec_other")
 
@@ -32,7 +33,8 @@ EXPORTS = ("wh_model_load", "wh_model_create", "wh_model_free", "wh_model_get_di
            "wh_model_export_tensor", "wh_ctx_create", "wh_ctx_free", "wh_last_error", "wh_get_timings",
            "wh_mel_frames", "wh_log_mel", "wh_encode", "wh_decode_greedy", "wh_transcribe_batch",
            "wh_transcribe_batch_device", "wh_longform_plan", "wh_transcribe_longform", "wh_profile_enable",
-           "wh_profile_get", "wh_synthetic_weights", "wh_abi_version", "wh_device_count")
+           "wh_profile_get", "wh_synthetic_weights", "wh_e4m3_quantize", "wh_e4m3_dequantize", "wh_abi_version",
+           "wh_device_count")
 
 
 class WhisperHipError(RuntimeError):
@@ -99,6 +101,10 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.wh_profile_enable.argtypes = [vp, C.c_int]
     L.wh_profile_get.argtypes = [vp, C.POINTER(C.c_double), i64p]
     L.wh_synthetic_weights.argtypes = [C.c_char_p, C.c_uint64, f32p, C.c_size_t, szp]
+    L.wh_e4m3_quantize.argtypes = [f32p, C.c_size_t, C.POINTER(C.c_uint8)]
+    L.wh_e4m3_quantize.restype = None
+    L.wh_e4m3_dequantize.argtypes = [C.POINTER(C.c_uint8), C.c_size_t, f32p]
+    L.wh_e4m3_dequantize.restype = None
     _lib = L
     return L
 
@@ -324,6 +330,21 @@ def synthetic_weights(preset: str, seed: int) -> np.ndarray:
     rc = L.wh_synthetic_weights(preset.encode(), seed, _f32(out), out.size, C.byref(n))
     if rc:
         raise WhisperHipError(rc, (L.wh_last_error(None) or b"").decode())
+    return out
+
+
+def e4m3_quantize(x: np.ndarray) -> np.ndarray:
+    """Host-only: f32 -> OCP e4m3fn codes exactly as WH_PREC_FP8 stores weights."""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty(x.shape, np.uint8)
+    load_library().wh_e4m3_quantize(_f32(x), x.size, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
+def e4m3_dequantize(codes: np.ndarray) -> np.ndarray:
+    codes = np.ascontiguousarray(codes, np.uint8)
+    out = np.empty(codes.shape, np.float32)
+    load_library().wh_e4m3_dequantize(codes.ctypes.data_as(C.POINTER(C.c_uint8)), codes.size, _f32(out))
     return out
 
 

@@ -136,7 +136,7 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
             Prof p(c, WH_KG_ENC_GEMM);
             GemmArgs g;
             g.A = c->xn; g.lda = d; g.W = L.qk_w; g.ldw = d; g.C = c->qk; g.ldc = 2 * d;
-            g.bias = L.qk_b; g.bias_mode = 1; g.M = (int)rows; g.N = (int)(2 * d); g.K = (int)d;
+            g.bias = L.qk_b; g.bias_mode = 1; g.wscale = L.qk_sc; g.M = (int)rows; g.N = (int)(2 * d); g.K = (int)d;
             wh_launch_gemm(s, prec, false, g);
         }
         {   // V^T[e][key] = W_v x^T + b_v: per-clip product with the weight as the row operand
@@ -145,7 +145,7 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
             g.A = L.v_w; g.lda = d; g.a_zs = 0;
             g.W = c->xn; g.ldw = d; g.w_zs = S * d;
             g.C = c->vT; g.ldc = c->ldv; g.c_zs = d * c->ldv;
-            g.bias = L.v_b; g.bias_mode = 2; g.M = (int)d; g.N = (int)S; g.K = (int)d; g.batch = nb;
+            g.bias = L.v_b; g.bias_mode = 2; g.wscale = L.v_sc; g.M = (int)d; g.N = (int)S; g.K = (int)d; g.batch = nb;
             wh_launch_gemm(s, prec, false, g);
         }
         {
@@ -156,7 +156,7 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
             Prof p(c, WH_KG_ENC_GEMM);
             GemmArgs g;
             g.A = c->att; g.lda = d; g.W = L.o_w; g.ldw = d; g.C = c->x; g.ldc = d;
-            g.bias = L.o_b; g.bias_mode = 1; g.R = c->x; g.ldr = d; g.M = (int)rows; g.N = (int)d; g.K = (int)d;
+            g.bias = L.o_b; g.bias_mode = 1; g.wscale = L.o_sc; g.R = c->x; g.ldr = d; g.M = (int)rows; g.N = (int)d; g.K = (int)d;
             wh_launch_gemm(s, prec, true, g);
         }
         { Prof p(c, WH_KG_ENC_GEMM); wh_launch_layernorm(s, prec, c->x, L.ln2_w, L.ln2_b, c->xn, rows, (int)d); }
@@ -164,14 +164,14 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
             Prof p(c, WH_KG_ENC_GEMM);
             GemmArgs g;
             g.A = c->xn; g.lda = d; g.W = L.fc1_w; g.ldw = d; g.C = c->hbuf; g.ldc = F;
-            g.bias = L.fc1_b; g.bias_mode = 1; g.act = 1; g.M = (int)rows; g.N = (int)F; g.K = (int)d;
+            g.bias = L.fc1_b; g.bias_mode = 1; g.wscale = L.fc1_sc; g.act = 1; g.M = (int)rows; g.N = (int)F; g.K = (int)d;
             wh_launch_gemm(s, prec, false, g);
         }
         {
             Prof p(c, WH_KG_ENC_GEMM);
             GemmArgs g;
             g.A = c->hbuf; g.lda = F; g.W = L.fc2_w; g.ldw = F; g.C = c->x; g.ldc = d;
-            g.bias = L.fc2_b; g.bias_mode = 1; g.R = c->x; g.ldr = d; g.M = (int)rows; g.N = (int)d; g.K = (int)F;
+            g.bias = L.fc2_b; g.bias_mode = 1; g.wscale = L.fc2_sc; g.R = c->x; g.ldr = d; g.M = (int)rows; g.N = (int)d; g.K = (int)F;
             wh_launch_gemm(s, prec, true, g);
         }
     }
@@ -249,6 +249,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
         d_logits = c->logits;
     }
 
+    const bool f8 = prec == WH_PREC_FP8;
     // cross-attention K/V of every decoder layer, once per clip: present.{i}.encoder.{key,value}
     // of the step-0 decoder run (src/main.rs:771-787)
     const long kv_stride = (long)nb * S * d;  // elements between consecutive [nb][S][d] planes
@@ -257,9 +258,14 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
         GemmArgs g;
         g.A = c->enc_out; g.lda = d; g.W = m->cross_kv_w; g.ldw = d;
         g.C = c->cross_kv; g.ldc = d; g.n_per = (int)d; g.c_ns = kv_stride;
-        g.bias = m->cross_kv_b; g.bias_mode = 1;
+        g.bias = m->cross_kv_b; g.bias_mode = 1; g.wscale = m->cross_kv_sc;
         g.M = nb * (int)S; g.N = (int)(D.dec_layers * 2 * d); g.K = (int)d;
         wh_launch_gemm(s, prec, false, g);
+        if (f8) {  // bf16 projection → e4m3 codes, one scale per (layer, K|V, clip, head)
+            const long planes = (long)D.dec_layers * 2 * nb;
+            hipMemsetAsync(c->kv_amax, 0, planes * D.n_heads * 4, s);
+            wh_launch_kv_quant(s, c->cross_kv, (unsigned*)c->kv_amax, c->cross_kv8, planes, (int)S, (int)d, D.n_heads);
+        }
     }
 
     DecodeState st;
@@ -279,7 +285,8 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     auto launch_step = [&](bool emits) {
         {   // token + position embedding → x, raw slab, row sums (one "tile")
             Prof pr(c, WH_KG_DEC_OTHER);
-            wh_launch_dec_embed(s, prec, m->tok_emb, m->dec_pos, c->feed, ld, c->pos, c->dx, c->dxs, c->lnpart, nb, (int)d, mpad);
+            wh_launch_dec_embed(s, prec, m->tok_emb, m->dec_pos, c->feed, ld, c->pos, c->dx, c->dxs, c->lnpart, nb, (int)d, mpad,
+                                f8 ? m->dec[0].ln1_w : nullptr);
         }
         for (int l = 0; l < D.dec_layers; l++) {
             const DecLayerDev& L = m->dec[l];
@@ -287,7 +294,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
             {   // LN1 ∘ Q|K|V projection
                 Prof pr(c, WH_KG_DEC_GEMM);
                 a = SkinnyArgs();
-                a.X = c->dxs; a.x_mpad = mpad; a.W = L.qkv_w; a.bias = L.qkv_b; a.C = c->dqkv; a.ldc = 3 * d;
+                a.X = c->dxs; a.x_mpad = mpad; a.W = L.qkv_w; a.bias = L.qkv_b; a.wscale = L.qkv_sc; a.C = c->dqkv; a.ldc = 3 * d;
                 a.M = nb; a.N = (int)(3 * d); a.K = (int)d;
                 a.ln_part = c->lnpart; a.ln_tiles = (l == 0) ? 1 : ln_tiles_d; a.ln_s = L.qkv_s;
                 wh_launch_dec_gemm(s, prec, false, a);
@@ -301,35 +308,42 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
             {   // self-attention out-proj + residual → x, raw slab, LN2 partials
                 Prof pr(c, WH_KG_DEC_GEMM);
                 a = SkinnyArgs();
-                a.X = c->datt; a.x_mpad = mpad; a.W = L.o_w; a.bias = L.o_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
+                a.X = c->datt; a.x_mpad = mpad; a.W = L.o_w; a.bias = L.o_b; a.wscale = L.o_sc; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
                 a.M = nb; a.N = (int)d; a.K = (int)d; a.xslab_out = c->dxs; a.stats_out = c->lnpart;
+                if (f8) a.xgamma = L.ln2_w;
                 wh_launch_dec_gemm(s, prec, true, a);
             }
             {   // LN2 ∘ cross-attention query
                 Prof pr(c, WH_KG_DEC_GEMM);
                 a = SkinnyArgs();
-                a.X = c->dxs; a.x_mpad = mpad; a.W = L.cq_w; a.bias = L.cq_b; a.C = c->dq; a.ldc = d; a.M = nb; a.N = (int)d; a.K = (int)d;
+                a.X = c->dxs; a.x_mpad = mpad; a.W = L.cq_w; a.bias = L.cq_b; a.wscale = L.cq_sc; a.C = c->dq; a.ldc = d; a.M = nb; a.N = (int)d; a.K = (int)d;
                 a.ln_part = c->lnpart; a.ln_tiles = ln_tiles_d; a.ln_s = L.cq_s;
                 wh_launch_dec_gemm(s, prec, false, a);
             }
             {
                 Prof pr(c, WH_KG_DEC_CROSS_ATTN);
-                wh_launch_dec_cross_attn(s, prec, c->dq, (char*)c->cross_kv + (2 * l) * kv_stride * esz,
-                                         (char*)c->cross_kv + (2 * l + 1) * kv_stride * esz, c->cpart, c->cml,
-                                         (int)S, (int)d, D.n_heads, c->cross_splits, nb);
+                if (f8)
+                    wh_launch_dec_cross_attn8(s, c->dq, (char*)c->cross_kv8 + (2 * l) * kv_stride, (char*)c->cross_kv8 + (2 * l + 1) * kv_stride,
+                                              c->kv_amax + (long)(2 * l) * nb * D.n_heads, c->kv_amax + (long)(2 * l + 1) * nb * D.n_heads,
+                                              c->cpart, c->cml, (int)S, (int)d, D.n_heads, c->cross_splits, nb);
+                else
+                    wh_launch_dec_cross_attn(s, prec, c->dq, (char*)c->cross_kv + (2 * l) * kv_stride * esz,
+                                             (char*)c->cross_kv + (2 * l + 1) * kv_stride * esz, c->cpart, c->cml,
+                                             (int)S, (int)d, D.n_heads, c->cross_splits, nb);
             }
             {   // merge of the key ranges ∘ cross-attention out-proj + residual → x, raw slab, LN3 partials
                 Prof pr(c, WH_KG_DEC_GEMM);
                 a = SkinnyArgs();
                 a.xpart = c->cpart; a.xml = c->cml; a.x_splits = c->cross_splits; a.x_heads = D.n_heads;
-                a.x_mpad = mpad; a.W = L.co_w; a.bias = L.co_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
+                a.x_mpad = mpad; a.W = L.co_w; a.bias = L.co_b; a.wscale = L.co_sc; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
                 a.M = nb; a.N = (int)d; a.K = (int)d; a.xslab_out = c->dxs; a.stats_out = c->lnpart;
+                if (f8) a.xgamma = L.ln3_w;
                 wh_launch_dec_gemm(s, prec, true, a);
             }
             {   // LN3 ∘ fc1 + GELU (slab output)
                 Prof pr(c, WH_KG_DEC_GEMM);
                 a = SkinnyArgs();
-                a.X = c->dxs; a.x_mpad = mpad; a.W = L.fc1_w; a.bias = L.fc1_b; a.act = 1; a.C = c->dh; a.c_mpad = mpad;
+                a.X = c->dxs; a.x_mpad = mpad; a.W = L.fc1_w; a.bias = L.fc1_b; a.wscale = L.fc1_sc; a.act = 1; a.C = c->dh; a.c_mpad = mpad;
                 a.M = nb; a.N = (int)F; a.K = (int)d;
                 a.ln_part = c->lnpart; a.ln_tiles = ln_tiles_d; a.ln_s = L.fc1_s;
                 wh_launch_dec_gemm(s, prec, false, a);
@@ -337,8 +351,9 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
             {   // fc2 + residual → x, raw slab, partials for the next layer's LN1 / the final LN
                 Prof pr(c, WH_KG_DEC_GEMM);
                 a = SkinnyArgs();
-                a.X = c->dh; a.x_mpad = mpad; a.W = L.fc2_w; a.bias = L.fc2_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
+                a.X = c->dh; a.x_mpad = mpad; a.W = L.fc2_w; a.bias = L.fc2_b; a.wscale = L.fc2_sc; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
                 a.M = nb; a.N = (int)d; a.K = (int)F; a.xslab_out = c->dxs; a.stats_out = c->lnpart;
+                if (f8) a.xgamma = (l + 1 < D.dec_layers) ? m->dec[l + 1].ln1_w : m->dec_ln_w;  // next consumer's LayerNorm
                 if (!emits && l == D.dec_layers - 1) { a.ticket = c->step_ticket; a.pos_w = c->pos; }  // prompt position: advance here
                 wh_launch_dec_gemm(s, prec, true, a);
             }
@@ -547,6 +562,9 @@ int wh_model_get_dims(const wh_model* m, wh_dims* out) {
 }
 int wh_model_precision(const wh_model* m) { return m ? m->prec : -1; }
 
+void wh_e4m3_quantize(const float* x, size_t n, uint8_t* codes) { for (size_t i = 0; i < n; i++) codes[i] = wh_e4m3_from_f32(x[i]); }
+void wh_e4m3_dequantize(const uint8_t* codes, size_t n, float* x) { for (size_t i = 0; i < n; i++) x[i] = wh_e4m3_to_f32(codes[i]); }
+
 int wh_model_export_tensor(const wh_model* m, const char* name, float* out, size_t cap, size_t* n_out) {
     if (!m || !name) return WH_ERR_ARG;
     auto it = m->index.find(name);
@@ -585,6 +603,8 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
     const size_t o_vT = cv.take(B * d * c->ldv * esz), o_att = cv.take(B * S * d * esz), o_h = cv.take(B * S * F * esz);
     const size_t o_enc = cv.take(B * S * d * esz), o_encf = cv.take(B * S * d * 4);
     const size_t o_ckv = cv.take(Ld * 2 * B * S * d * esz);
+    const bool f8 = m->prec == WH_PREC_FP8;
+    const size_t o_ckv8 = f8 ? cv.take(Ld * 2 * B * S * d) : 0, o_kvam = f8 ? cv.take(Ld * 2 * B * H * 4) : 0;
     const size_t o_sk = cv.take(Ld * B * H * TC * WH_HEAD_DIM * esz), o_sv = cv.take(Ld * B * H * TC * WH_HEAD_DIM * esz);
     const size_t MP = align_up(B, 16);  // slab-layout activations: [K/32][MP][32]
     const size_t o_dx = cv.take(B * d * 4), o_dxn = cv.take(MP * d * esz), o_dqkv = cv.take(B * 3 * d * esz);
@@ -607,6 +627,7 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
     c->melT = w + o_melT; c->h1 = w + o_h1; c->x = (float*)(w + o_x); c->xn = w + o_xn; c->qk = w + o_qk;
     c->vT = w + o_vT; c->att = w + o_att; c->hbuf = w + o_h; c->enc_out = w + o_enc; c->enc_out_f32 = (float*)(w + o_encf);
     c->cross_kv = w + o_ckv; c->self_k = w + o_sk; c->self_v = w + o_sv;
+    if (f8) { c->cross_kv8 = w + o_ckv8; c->kv_amax = (float*)(w + o_kvam); }
     c->dx = (float*)(w + o_dx); c->dxn = w + o_dxn; c->dxs = w + o_dxs; c->lnpart = (float*)(w + o_lnp); c->dqkv = w + o_dqkv; c->datt = w + o_datt; c->dq = w + o_dq; c->dh = w + o_dh;
     c->cpart = (float*)(w + o_cpart); c->cml = (float*)(w + o_cml); c->part_val = (float*)(w + o_pv); c->part_idx = (int*)(w + o_pi);
     c->feed = (int*)(w + o_feed); c->out_tokens = (int*)(w + o_out); c->n_out = (int*)(w + o_nout); c->done = (int*)(w + o_done);

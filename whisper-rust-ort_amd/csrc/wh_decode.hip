@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_dec_embed(const T* __restrict__ tok_emb
                                                    const int* __restrict__ feed, int feed_ld,
                                                    const int* __restrict__ pos_p, float* __restrict__ x,
                                                    T* __restrict__ xslab, float* __restrict__ stats, int rows, int d,
-                                                   int mpad) {
+                                                   int mpad, const float* __restrict__ xgamma) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63, pos = *pos_p;
@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void k_dec_embed(const T* __restrict__ tok_emb
         f32x4 p = *reinterpret_cast<const f32x4*>(pr + c);
         f32x4 v = {cvt_in<T>(er[c]) + p[0], cvt_in<T>(er[c + 1]) + p[1], cvt_in<T>(er[c + 2]) + p[2], cvt_in<T>(er[c + 3]) + p[3]};
         *reinterpret_cast<f32x4*>(x + (long)row * d + c) = v;
-        store4(xslab + slab_idx(row, c, mpad), v[0], v[1], v[2], v[3]);
+        f32x4 g = {1, 1, 1, 1};
+        if (xgamma) g = *reinterpret_cast<const f32x4*>(xgamma + c);  // fp8 mode: the first LayerNorm's γ rides on the slab copy
+        store4(xslab + slab_idx(row, c, mpad), v[0] * g[0], v[1] * g[1], v[2] * g[2], v[3] * g[3]);
         s1 += (v[0] + v[1]) + (v[2] + v[3]);
         s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
@@ -137,7 +139,37 @@ __device__ __forceinline__ f32x4 partials_merge(const SkinnyArgs& a, PartRaw<SP>
     return acc;
 }
 
-template <typename T, typename TO, int MT, int NW, int XP>  // XP > 0: X from XP-bounded attention partials
+// Weight operand of one k-step.  Native dtype: 8 consecutive k per lane (one MFMA per load).  e4m3 codes: 8 per lane
+// (fp8x8_t, one MFMA) or 16 per lane (fp8x16_t: one 16-byte load feeds two MFMAs — half the load instructions for
+// the same bytes); codes are dequantised in registers with v_cvt_scalef32_pk_bf16_fp8 (byte j of the dword is
+// element j, exact: tools/fp8_check.hip).  A k-step covers 4 * KW k-values; within it lane group fg holds
+// k = fg*KW .. fg*KW+KW-1, sub-fragment j the eight starting at 8j — the activation operand follows the same map.
+struct fp8x8_t { unsigned char v; };
+struct fp8x16_t { unsigned char v; };
+template <typename T, typename TW> struct WTraits { static constexpr int KW = 8; };
+template <> struct WTraits<bf16, fp8x16_t> { static constexpr int KW = 16; };
+
+__device__ __forceinline__ bf16x8 cvt8_e4m3_bf16(unsigned lo, unsigned hi) {
+    const bf16x2 a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, true);
+    const bf16x2 c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true);
+    return bf16x8{a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+}
+template <typename T, typename TW>
+__device__ __forceinline__ void load_wfrags(const TW* p, typename FragT<T>::type (&out)[WTraits<T, TW>::KW / 8]) {
+    if constexpr (sizeof(TW) == sizeof(T)) {
+        out[0] = load_frag<T>(reinterpret_cast<const T*>(p));
+    } else if constexpr (WTraits<T, TW>::KW == 8) {
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+        const u32x2 u = *reinterpret_cast<const u32x2*>(p);
+        out[0] = cvt8_e4m3_bf16(u.x, u.y);
+    } else {
+        const wh_u32x4 u = *reinterpret_cast<const wh_u32x4*>(p);
+        out[0] = cvt8_e4m3_bf16(u.x, u.y);
+        out[1] = cvt8_e4m3_bf16(u.z, u.w);
+    }
+}
+
+template <typename T, typename TO, int MT, int NW, int XP, typename TW = T>  // XP > 0: X from XP-bounded attention partials
 __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -146,27 +178,33 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
     const int m0 = blockIdx.y * MT * 16;  // first row of this workgroup's row group
     int nrow = n0 + fl;
     if (nrow > a.N - 1) nrow = a.N - 1;
-    const int kspan = a.K / NW, kb = wave * kspan, iters = kspan >> 5;
-    const T* wp = (const T*)a.W + (long)nrow * a.K + kb + fg * 8;
-    const T* xp = XP > 0 ? nullptr : (const T*)a.X + ((long)(kb >> 5) * a.x_mpad + m0 + fl) * 32 + fg * 8;
-    const long xstep = (long)a.x_mpad * 32;
-    constexpr int DEPTH = 8;
-    typename FragT<T>::type wq[DEPTH], xq[DEPTH][MT];
+    constexpr int KW = WTraits<T, TW>::KW, SUB = KW / 8, KSTEP = 4 * KW;  // k-values per lane / MFMAs / k-values per step
+    const int kspan = a.K / NW, kb = wave * kspan, iters = kspan / KSTEP;
+    const TW* wp = (const TW*)a.W + (long)nrow * a.K + kb + fg * KW;
+    // activation operand of (step i, sub-fragment j): slab (kb + i*KSTEP + fg*KW) / 32, offset (fg*KW) % 32 + 8j
+    const long xstep = (long)a.x_mpad * 32 * (KSTEP / 32);
+    const T* xp = XP > 0 ? nullptr : (const T*)a.X + ((long)((kb + fg * KW) >> 5) * a.x_mpad + m0 + fl) * 32 + ((fg * KW) & 31);
+    constexpr int DEPTH = 8 / SUB;
+    typename FragT<T>::type wq[DEPTH][SUB], xq[DEPTH][SUB][MT];
 #pragma unroll
     for (int i = 0; i < DEPTH; i++)
         if (i < iters) {
-            wq[i] = load_frag<T>(wp + i * 32);
+            load_wfrags<T, TW>(wp + i * KSTEP, wq[i]);
             if constexpr (XP == 0) {
 #pragma unroll
-                for (int t = 0; t < MT; t++) xq[i][t] = load_frag<T>(xp + i * xstep + t * 512);
+                for (int j = 0; j < SUB; j++)
+#pragma unroll
+                    for (int t = 0; t < MT; t++) xq[i][j][t] = load_frag<T>(xp + i * xstep + t * 512 + 8 * j);
             }
         }
     // epilogue operands (wave w finishes row-tile w): fetched now, used last
-    f32x4 pre_bias = {0, 0, 0, 0}, pre_r = {0, 0, 0, 0};
+    f32x4 pre_bias = {0, 0, 0, 0}, pre_r = {0, 0, 0, 0}, pre_ws = {1, 1, 1, 1}, pre_g = {1, 1, 1, 1};
     const int en = n0 + 4 * fg, em = m0 + wave * 16 + fl;
     const bool ep_ok = wave < MT && en < a.N && em < a.M;
     if (ep_ok) {
         if (a.bias) pre_bias = *reinterpret_cast<const f32x4*>(a.bias + en);
+        if (a.wscale) pre_ws = *reinterpret_cast<const f32x4*>(a.wscale + en);
+        if (a.xgamma) pre_g = *reinterpret_cast<const f32x4*>(a.xgamma + en);
         if (a.R) pre_r = *reinterpret_cast<const f32x4*>(a.R + (long)em * a.ldr + en);
     }
     // LayerNorm folded in: reduce the producer's per-tile partial sums of this row group to mean / rstd
@@ -230,27 +268,40 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
             }
         }
         __syncthreads();
-        const T* xl = Xs + ((long)(kb >> 5) * 16 + fl) * 32 + fg * 8;
+        const T* xl = Xs + ((long)((kb + fg * KW) >> 5) * 16 + fl) * 32 + ((fg * KW) & 31);
+        constexpr int lstep = 512 * (KSTEP / 32);
 #pragma unroll
         for (int i = 0; i < DEPTH; i++)
-            if (i < iters) mma16(acc[0], wq[i], load_frag<T>(xl + i * 512));
-        for (int i = DEPTH; i < iters; i++) mma16(acc[0], load_frag<T>(wp + i * 32), load_frag<T>(xl + i * 512));  // deep K tail
+            if (i < iters) {
+#pragma unroll
+                for (int j = 0; j < SUB; j++) mma16(acc[0], wq[i][j], load_frag<T>(xl + i * lstep + 8 * j));
+            }
+        for (int i = DEPTH; i < iters; i++) {  // deep K tail
+            typename FragT<T>::type wt[SUB];
+            load_wfrags<T, TW>(wp + i * KSTEP, wt);
+#pragma unroll
+            for (int j = 0; j < SUB; j++) mma16(acc[0], wt[j], load_frag<T>(xl + i * lstep + 8 * j));
+        }
     } else
     for (int c0 = 0; c0 < iters; c0 += DEPTH) {
         if (c0 > 0) {
 #pragma unroll
             for (int i = 0; i < DEPTH; i++)
                 if (c0 + i < iters) {
-                    wq[i] = load_frag<T>(wp + (c0 + i) * 32);
+                    load_wfrags<T, TW>(wp + (c0 + i) * KSTEP, wq[i]);
 #pragma unroll
-                    for (int t = 0; t < MT; t++) xq[i][t] = load_frag<T>(xp + (c0 + i) * xstep + t * 512);
+                    for (int j = 0; j < SUB; j++)
+#pragma unroll
+                        for (int t = 0; t < MT; t++) xq[i][j][t] = load_frag<T>(xp + (c0 + i) * xstep + t * 512 + 8 * j);
                 }
         }
 #pragma unroll
         for (int i = 0; i < DEPTH; i++)
             if (c0 + i < iters) {
 #pragma unroll
-                for (int t = 0; t < MT; t++) mma16(acc[t], wq[i], xq[i][t]);  // D rows = n (4*fg + r), col = m (fl)
+                for (int j = 0; j < SUB; j++)
+#pragma unroll
+                    for (int t = 0; t < MT; t++) mma16(acc[t], wq[i][j], xq[i][j][t]);  // D rows = n (4*fg + r), col = m (fl)
             }
     }
     f32x4* red = reinterpret_cast<f32x4*>(smem_raw);
@@ -267,13 +318,14 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
+            s[e] *= pre_ws[e];  // fp8 weights: the channel scale (1 otherwise)
             v[e] = a.ln_part ? ln_rstd * (s[e] - ln_mean * ln_sv[e]) + pre_bias[e] : s[e] + pre_bias[e];
             if (a.act == 1) v[e] = gelu_erf(v[e]);
             v[e] += pre_r[e];
         }
         TO* dst = a.c_mpad ? (TO*)a.C + slab_idx(em, en, a.c_mpad) : (TO*)a.C + (long)em * a.ldc + en;
         store4(dst, v[0], v[1], v[2], v[3]);
-        if (a.xslab_out) store4((T*)a.xslab_out + slab_idx(em, en, a.x_mpad), v[0], v[1], v[2], v[3]);
+        if (a.xslab_out) store4((T*)a.xslab_out + slab_idx(em, en, a.x_mpad), v[0] * pre_g[0], v[1] * pre_g[1], v[2] * pre_g[2], v[3] * pre_g[3]);
     }
     if (a.stats_out && wave < MT) {
         // this column tile's {sum x, sum x^2} per row: 4 values per lane, then the 4 lane groups of the row
@@ -287,7 +339,7 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
             }
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const float v = s[e] + pre_bias[e] + pre_r[e];  // producers have no activation
+                const float v = s[e] * pre_ws[e] + pre_bias[e] + pre_r[e];  // producers have no activation
                 s1 += v;
                 s2 += v * v;
             }
@@ -488,7 +540,6 @@ __global__ __launch_bounds__(64) void k_dec_self_attn(const T* __restrict__ qkv,
                                                       const int* __restrict__ pos_p, int d, int n_heads, int tc,
                                                       int mpad) {
     constexpr int HD = WH_HEAD_DIM;
-    constexpr int EPC = 16 / (int)sizeof(T);
     typedef typename FragT<T>::type frag_t;
     __shared__ __attribute__((aligned(16))) float qs[HD];
     __shared__ __attribute__((aligned(16))) float sc[512];
@@ -748,7 +799,7 @@ void set_max_smem(K kernel, size_t bytes) {
     }
 }
 
-template <typename T, typename TO, int NW>
+template <typename T, typename TO, int NW, typename TW>
 void launch_dec_gemm_mt(hipStream_t s, const SkinnyArgs& a) {
     const int n_tiles = (a.N + 15) / 16;
     // rows per workgroup: 64, or 32 when K is deep (every workgroup pulls its rows of X through L2; halving
@@ -763,44 +814,50 @@ void launch_dec_gemm_mt(hipStream_t s, const SkinnyArgs& a) {
     if (a.xpart) {  // X merged from attention partials: 16-row groups only (the merge is per-lane work)
         dim3 g1(n_tiles, (a.M + 15) / 16);
         const size_t sm1 = (size_t)NW * 64 * 16 + 4 * 16 * 2 * 4 + (size_t)16 * a.K * sizeof(T);  // + merged X tile
-        if (a.x_splits <= 4) { set_max_smem(k_dec_gemm<T, TO, 1, NW, 4>, sm1); hipLaunchKernelGGL((k_dec_gemm<T, TO, 1, NW, 4>), g1, dim3(NW * 64), sm1, s, a); }
-        else if (a.x_splits <= 8) { set_max_smem(k_dec_gemm<T, TO, 1, NW, 8>, sm1); hipLaunchKernelGGL((k_dec_gemm<T, TO, 1, NW, 8>), g1, dim3(NW * 64), sm1, s, a); }
-        else if (a.x_splits <= 16) { set_max_smem(k_dec_gemm<T, TO, 1, NW, 16>, sm1); hipLaunchKernelGGL((k_dec_gemm<T, TO, 1, NW, 16>), g1, dim3(NW * 64), sm1, s, a); }
-        else { set_max_smem(k_dec_gemm<T, TO, 1, NW, 32>, sm1); hipLaunchKernelGGL((k_dec_gemm<T, TO, 1, NW, 32>), g1, dim3(NW * 64), sm1, s, a); }
+        if (a.x_splits <= 4) { set_max_smem(k_dec_gemm<T, TO, 1, NW, 4, TW>, sm1); hipLaunchKernelGGL((k_dec_gemm<T, TO, 1, NW, 4, TW>), g1, dim3(NW * 64), sm1, s, a); }
+        else if (a.x_splits <= 8) { set_max_smem(k_dec_gemm<T, TO, 1, NW, 8, TW>, sm1); hipLaunchKernelGGL((k_dec_gemm<T, TO, 1, NW, 8, TW>), g1, dim3(NW * 64), sm1, s, a); }
+        else if (a.x_splits <= 16) { set_max_smem(k_dec_gemm<T, TO, 1, NW, 16, TW>, sm1); hipLaunchKernelGGL((k_dec_gemm<T, TO, 1, NW, 16, TW>), g1, dim3(NW * 64), sm1, s, a); }
+        else { set_max_smem(k_dec_gemm<T, TO, 1, NW, 32, TW>, sm1); hipLaunchKernelGGL((k_dec_gemm<T, TO, 1, NW, 32, TW>), g1, dim3(NW * 64), sm1, s, a); }
         return;
     }
     switch (mt) {
-        case 1: hipLaunchKernelGGL((k_dec_gemm<T, TO, 1, NW, 0>), grid, dim3(NW * 64), sm, s, a); break;
-        case 2: hipLaunchKernelGGL((k_dec_gemm<T, TO, 2, NW, 0>), grid, dim3(NW * 64), sm, s, a); break;
-        case 3: hipLaunchKernelGGL((k_dec_gemm<T, TO, 3, NW, 0>), grid, dim3(NW * 64), sm, s, a); break;
-        default: hipLaunchKernelGGL((k_dec_gemm<T, TO, 4, NW, 0>), grid, dim3(NW * 64), sm, s, a); break;
+        case 1: hipLaunchKernelGGL((k_dec_gemm<T, TO, 1, NW, 0, TW>), grid, dim3(NW * 64), sm, s, a); break;
+        case 2: hipLaunchKernelGGL((k_dec_gemm<T, TO, 2, NW, 0, TW>), grid, dim3(NW * 64), sm, s, a); break;
+        case 3: hipLaunchKernelGGL((k_dec_gemm<T, TO, 3, NW, 0, TW>), grid, dim3(NW * 64), sm, s, a); break;
+        default: hipLaunchKernelGGL((k_dec_gemm<T, TO, 4, NW, 0, TW>), grid, dim3(NW * 64), sm, s, a); break;
     }
 }
 
-template <typename T, typename TO>
+template <typename T, typename TO, typename TW>
 void launch_dec_gemm_split(hipStream_t s, const SkinnyArgs& a) {
     // K is split over the waves of a workgroup: 8 ways when it is deep, else 4 (K % 128 == 0 always
     // holds: d_model and ffn are multiples of 128, checked at model load)
     // (X from attention partials: 8 ways too — fewer fragments to merge per lane)
-    if ((a.K >= 2048 || a.xpart) && a.K % 256 == 0) launch_dec_gemm_mt<T, TO, 8>(s, a);
-    else launch_dec_gemm_mt<T, TO, 4>(s, a);
+    if ((a.K >= 2048 || a.xpart) && a.K % 256 == 0) launch_dec_gemm_mt<T, TO, 8, TW>(s, a);
+    else launch_dec_gemm_mt<T, TO, 4, TW>(s, a);
 }
 
 }  // namespace
 
 void wh_launch_dec_gemm(hipStream_t s, int prec, bool out_f32, const SkinnyArgs& a) {
-    if (prec == WH_PREC_F32) launch_dec_gemm_split<float, float>(s, a);
-    else if (out_f32) launch_dec_gemm_split<bf16, float>(s, a);
-    else launch_dec_gemm_split<bf16, bf16>(s, a);
+    if (prec == WH_PREC_F32) launch_dec_gemm_split<float, float, float>(s, a);
+    else if (prec == WH_PREC_FP8 && a.wscale) {  // e4m3 weight codes, bf16 activations
+        // 16 codes per lane per load when every wave's K share is a multiple of 64, else 8
+        const int nw = ((a.K >= 2048 || a.xpart) && a.K % 256 == 0) ? 8 : 4;
+        const bool wide = (a.K / nw) % 64 == 0;
+        if (wide) { if (out_f32) launch_dec_gemm_split<bf16, float, fp8x16_t>(s, a); else launch_dec_gemm_split<bf16, bf16, fp8x16_t>(s, a); }
+        else { if (out_f32) launch_dec_gemm_split<bf16, float, fp8x8_t>(s, a); else launch_dec_gemm_split<bf16, bf16, fp8x8_t>(s, a); }
+    } else if (out_f32) launch_dec_gemm_split<bf16, float, bf16>(s, a);
+    else launch_dec_gemm_split<bf16, bf16, bf16>(s, a);
 }
 
 void wh_launch_dec_embed(hipStream_t s, int prec, const void* tok_emb, const float* pos_emb, const int* feed, int feed_ld,
-                         const int* pos_p, float* x, void* xslab, float* stats, int rows, int d, int mpad) {
+                         const int* pos_p, float* x, void* xslab, float* stats, int rows, int d, int mpad, const float* xgamma) {
     dim3 grid((rows + 3) / 4);
     if (prec == WH_PREC_F32)
-        hipLaunchKernelGGL(k_dec_embed<float>, grid, dim3(256), 0, s, (const float*)tok_emb, pos_emb, feed, feed_ld, pos_p, x, (float*)xslab, stats, rows, d, mpad);
+        hipLaunchKernelGGL(k_dec_embed<float>, grid, dim3(256), 0, s, (const float*)tok_emb, pos_emb, feed, feed_ld, pos_p, x, (float*)xslab, stats, rows, d, mpad, xgamma);
     else
-        hipLaunchKernelGGL(k_dec_embed<bf16>, grid, dim3(256), 0, s, (const bf16*)tok_emb, pos_emb, feed, feed_ld, pos_p, x, (bf16*)xslab, stats, rows, d, mpad);
+        hipLaunchKernelGGL(k_dec_embed<bf16>, grid, dim3(256), 0, s, (const bf16*)tok_emb, pos_emb, feed, feed_ld, pos_p, x, (bf16*)xslab, stats, rows, d, mpad, xgamma);
 }
 
 template <typename T>

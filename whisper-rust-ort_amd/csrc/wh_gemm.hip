@@ -130,12 +130,20 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         TO* crow = C + mb * g.c_bs + mi * g.ldc;
         const float* rrow = R ? R + mb * g.r_bs + mi * g.ldr : nullptr;
         const float bm = (g.bias && g.bias_mode == 2) ? g.bias[m] : 0.0f;
+        const float wm = (g.wscale && g.bias_mode == 2) ? g.wscale[m] : 1.0f;
 #pragma unroll
         for (int j = 0; j < TN; j++) {
             const int n = n0 + wc * (BN / 2) + j * 16 + fg * 4;
             if (n >= g.N) continue;
             const long nc = (long)(n / g.n_per) * g.c_ns + (n % g.n_per);
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (g.wscale) {  // fp8 weights: code-valued operand, the channel scale is applied here in f32
+                if (g.bias_mode == 2) { v[0] *= wm; v[1] *= wm; v[2] *= wm; v[3] *= wm; }
+                else {
+                    f32x4 w4 = *reinterpret_cast<const f32x4*>(g.wscale + n);
+                    v[0] *= w4[0]; v[1] *= w4[1]; v[2] *= w4[2]; v[3] *= w4[3];
+                }
+            }
             if (g.bias && g.bias_mode == 1) {
                 f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
                 v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];

@@ -13,6 +13,8 @@ struct EncLayerDev {
     void *qk_w, *v_w, *o_w, *fc1_w, *fc2_w;
     float *qk_b, *v_b, *o_b, *fc1_b, *fc2_b;
     float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    // WH_PREC_FP8: the matrices above hold the e4m3 code VALUES (exact in bf16); these are the per-output-channel scales
+    float *qk_sc = nullptr, *v_sc = nullptr, *o_sc = nullptr, *fc1_sc = nullptr, *fc2_sc = nullptr;
 };
 struct DecLayerDev {
     void *qkv_w, *o_w, *cq_w, *co_w, *fc1_w, *fc2_w;
@@ -20,6 +22,10 @@ struct DecLayerDev {
     float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *ln3_w, *ln3_b;
     // LayerNorm folded into the consumer GEMMs: qkv_w/cq_w/fc1_w hold W ⊙ γ, *_b hold c[n], *_s hold s[n]
     float *qkv_s, *cq_s, *fc1_s;
+    // WH_PREC_FP8: every matrix above is raw e4m3 codes [N][K] (one byte each) with these per-output-channel scales;
+    // LayerNorm's γ is then applied on the activation side (the producers write x ⊙ γ_next into the slab) and
+    // *_s hold sum_k γ[k] * W[n][k], *_b hold c[n], both of the dequantised weights
+    float *qkv_sc = nullptr, *o_sc = nullptr, *cq_sc = nullptr, *co_sc = nullptr, *fc1_sc = nullptr, *fc2_sc = nullptr;
 };
 
 struct wh_model {
@@ -37,7 +43,8 @@ struct wh_model {
     void *conv1_w = nullptr, *conv2_w = nullptr, *tok_emb = nullptr, *cross_kv_w = nullptr;
     float *conv1_b = nullptr, *conv2_b = nullptr, *enc_pos = nullptr, *dec_pos = nullptr, *cross_kv_b = nullptr;
     float *enc_ln_w = nullptr, *enc_ln_b = nullptr, *dec_ln_w = nullptr, *dec_ln_b = nullptr;
-    void* lm_w = nullptr;  // tied embedding ⊙ final-LN γ (LM head operand)
+    float* cross_kv_sc = nullptr;  // WH_PREC_FP8: scales of the cross K/V projection rows [Ld][2][d]
+    void* lm_w = nullptr;  // tied embedding ⊙ final-LN γ (LM head operand); WH_PREC_FP8: the embedding itself (γ on the activation side)
     float *lm_s = nullptr, *lm_c = nullptr;
     std::vector<EncLayerDev> enc;
     std::vector<DecLayerDev> dec;
@@ -95,6 +102,8 @@ struct wh_ctx {
     float* enc_out_f32 = nullptr;  // [B][S][d] f32 (API output)
     int ldv = 0;
     void* cross_kv = nullptr;   // [Ld][2][B][S][d]
+    void* cross_kv8 = nullptr;  // WH_PREC_FP8: the same planes as e4m3 codes (cross_kv is then the bf16 staging copy)
+    float* kv_amax = nullptr;   // WH_PREC_FP8: [Ld][2][B][H] max|.| of each head's block (scale = amax / 448)
     void *self_k = nullptr, *self_v = nullptr;  // [Ld][B][H][TC][64]
     // decode step buffers
     float* dx = nullptr;        // [B][d]
@@ -124,4 +133,6 @@ int wh_model_build(const wh_dims& dims, std::vector<float>&& master, int device,
 void wh_synth_weights(const wh_dims& dims, uint64_t seed, std::vector<float>& out);
 void wh_tensor_table(const wh_dims& dims, std::vector<std::pair<std::string, std::vector<int64_t>>>& out);
 bool wh_preset_dims(const std::string& name, wh_dims* out);
+uint8_t wh_e4m3_from_f32(float x);
+float wh_e4m3_to_f32(uint8_t c);
 int wh_load_model_dir(const std::string& dir, wh_dims* dims, std::vector<float>& master);

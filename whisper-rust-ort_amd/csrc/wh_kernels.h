@@ -13,6 +13,7 @@ struct GemmArgs {
     long ldc = 0, c_bs = 0, c_zs = 0;
     const float* bias = nullptr;
     int bias_mode = 0;         // 0 none, 1 per column n, 2 per row m
+    const float* wscale = nullptr;  // WH_PREC_FP8: accumulator scale (the weight's per-output-channel scale), indexed like bias
     const float* R = nullptr;  // f32 residual / positional table, same row addressing with ldr, r_bs
     long ldr = 0, r_bs = 0, r_zs = 0;
     int act = 0;               // 1 = erf GELU (applied before the residual add)
@@ -28,6 +29,10 @@ struct SkinnyArgs {
     int x_mpad = 64;
     const void* W = nullptr;   // [N][K]
     const float* bias = nullptr;
+    // WH_PREC_FP8: W holds e4m3 codes (one byte per element, dequantised in registers to the bf16 MFMA operand) and
+    // the accumulator is multiplied by wscale[n] before everything else
+    const float* wscale = nullptr;
+    const float* xgamma = nullptr;  // WH_PREC_FP8 producers: xslab_out receives v * xgamma[n] (the next LayerNorm's γ)
     const float* R = nullptr;  // residual f32 [M][ldr]
     long ldr = 0;
     void* C = nullptr;         // output: row-major [M][ldc] (c_mpad == 0) or slab [N/32][c_mpad][32]
@@ -94,7 +99,7 @@ void wh_launch_enc_attn(hipStream_t s, int prec, const void* qk, const void* vT,
 
 void wh_launch_dec_gemm(hipStream_t s, int prec, bool out_f32, const SkinnyArgs& a);
 void wh_launch_dec_embed(hipStream_t s, int prec, const void* tok_emb, const float* pos_emb, const int* feed, int feed_ld,
-                         const int* pos_p, float* x, void* xslab, float* stats, int rows, int d, int mpad);
+                         const int* pos_p, float* x, void* xslab, float* stats, int rows, int d, int mpad, const float* xgamma);
 void wh_launch_lm_head(hipStream_t s, int prec, const SkinnyArgs& a);
 void wh_launch_argmax_finish(hipStream_t s, const float* part_val, const int* part_idx, int n_tiles, int* pos_p,
                              int* ticket, const DecodeState& st, int B);
@@ -102,6 +107,12 @@ void wh_launch_dec_self_attn(hipStream_t s, int prec, const void* qkv, void* kc,
                              int d, int n_heads, int tc, int B, int mpad);
 void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void* ck, const void* cv, float* part,
                               float* ml, int S, int d, int n_heads, int splits, int B);
+
+// WH_PREC_FP8 (wh_fp8.hip)
+void wh_launch_kv_quant(hipStream_t s, const void* kv_bf16, unsigned* amax, void* kv8, long planes_x_clips, int S, int d,
+                        int n_heads);
+void wh_launch_dec_cross_attn8(hipStream_t s, const void* q, const void* ck, const void* cv, const float* amax_k,
+                               const float* amax_v, float* part, float* ml, int S, int d, int n_heads, int splits, int B);
 
 extern int wh_dbg_cross_unroll;
 extern int wh_dbg_lm_blocks_per_cu;

@@ -322,7 +322,50 @@ static inline uint16_t f32_to_bf16(float f) {  // round-to-nearest-even, NaN kep
 
 static inline float bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
+// ---- OCP e4m3fn (1-4-3, bias 7, max 448, no infinities): round to nearest even, saturating.  Bit-identical
+// twins: modelspec.quantize_e4m3 (numpy), oracle/whisper_oracle.c e4m3_from_f32; the gfx950 conversion
+// instructions agree with both on every input (tools/fp8_check.hip).
+uint8_t wh_e4m3_from_f32(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const uint8_t sign = (uint8_t)((u >> 24) & 0x80);
+    if (x != x) return 0x7F;
+    float a = fabsf(x);
+    if (a > 448.0f) a = 448.0f;
+    if (a >= 0.015625f) {  // normal: RNE at mantissa bit 20
+        memcpy(&u, &a, 4);
+        u += 0x7FFFFu + ((u >> 20) & 1u);
+        uint32_t code = (((u >> 23) - 120u) << 3) | ((u >> 20) & 7u);
+        if (code > 0x7Eu) code = 0x7Eu;
+        return (uint8_t)(code | sign);
+    }
+    return (uint8_t)((uint32_t)nearbyint((double)a * 512.0) | sign);  // multiples of 2^-9; 8 = first normal
+}
+float wh_e4m3_to_f32(uint8_t c) {
+    const int e = (c >> 3) & 15, mnt = c & 7;
+    float mag = e == 0 ? (float)mnt * 0.001953125f : ldexpf((float)(8 + mnt), e - 10);
+    if ((c & 0x7F) == 0x7F) mag = NAN;
+    return (c & 0x80) ? -mag : mag;
+}
+
 namespace {
+// rows of a Linear weight as e4m3 codes + one scale per row: scale = max|w| / 448 (1 for a zero row),
+// code = e4m3(w / scale); `rscale` (a power of two: 1 or head_dim^-0.5) only multiplies the scale
+struct QRows {
+    std::vector<uint8_t> codes;
+    std::vector<float> scale;
+};
+void quantize_rows(const float* W, size_t rows, size_t cols, float rscale, QRows& q, size_t row0, size_t total_rows) {
+    if (q.codes.size() != total_rows * cols) { q.codes.assign(total_rows * cols, 0); q.scale.assign(total_rows, 1.0f); }
+    for (size_t r = 0; r < rows; r++) {
+        float amax = 0.0f;
+        for (size_t k = 0; k < cols; k++) amax = std::max(amax, fabsf(W[r * cols + k]));
+        const float sc = amax > 0.0f ? amax / 448.0f : 1.0f;
+        for (size_t k = 0; k < cols; k++) q.codes[(row0 + r) * cols + k] = wh_e4m3_from_f32(W[r * cols + k] / sc);
+        q.scale[row0 + r] = sc * rscale;
+    }
+}
+
 struct Stager {
     std::vector<char> host;
     size_t esz;
@@ -347,6 +390,19 @@ struct Stager {
             for (size_t c = 0; c < cols; c++) d[c] = f32_to_bf16(src[c] * scale);
         }
     }
+    size_t put_bytes(const uint8_t* src, size_t n) {
+        size_t off = reserve(n);
+        memcpy(host.data() + off, src, n);
+        return off;
+    }
+    // e4m3 code VALUES as a bf16 matrix (exact): the encoder-side GEMM keeps its bf16 operand path and
+    // multiplies the accumulator by the row scale
+    size_t put_codes_bf16(const QRows& q, size_t rows, size_t cols) {
+        size_t off = reserve(rows * cols * 2);
+        uint16_t* d = (uint16_t*)(host.data() + off);
+        for (size_t i = 0; i < rows * cols; i++) d[i] = f32_to_bf16(wh_e4m3_to_f32(q.codes[i]));
+        return off;
+    }
     size_t put_f32(const float* src, size_t n, float scale = 1.0f) {
         size_t off = reserve(n * 4);
         float* d = (float*)(host.data() + off);
@@ -357,7 +413,7 @@ struct Stager {
 }  // namespace
 
 int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device, int precision, wh_model** out) {
-    if (precision != WH_PREC_F32 && precision != WH_PREC_BF16) {
+    if (precision != WH_PREC_F32 && precision != WH_PREC_BF16 && precision != WH_PREC_FP8) {
         wh_set_error("unsupported precision %d", precision);
         return WH_ERR_UNSUPPORTED;
     }
@@ -399,6 +455,8 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     const float qs = 1.0f / sqrtf((float)WH_HEAD_DIM);  // 0.125: exact, folded into W_q, b_q
     Stager st(m->esz);
     std::vector<float> tmp;
+    const bool f8 = precision == WH_PREC_FP8;
+    const size_t NONE = (size_t)-1;
 
     // conv weights tap-major: Wr[o][k*Cin + c] = W[o][c][k]
     auto conv_reorder = [&](const float* w, size_t cout, size_t cin, size_t kpad) {
@@ -415,26 +473,42 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     size_t o_conv2 = conv_reorder(T(e + ".conv2.weight"), d, d, 3 * d);
     size_t o_conv2b = st.put_f32(T(e + ".conv2.bias"), d);
     size_t o_encpos = st.put_f32(T(e + ".embed_positions.weight"), (size_t)c.n_audio_ctx * d);
-    struct EncOff { size_t qk, qkb, v, vb, o, ob, f1, f1b, f2, f2b, l1w, l1b, l2w, l2b; };
+    struct EncOff { size_t qk, qkb, v, vb, o, ob, f1, f1b, f2, f2b, l1w, l1b, l2w, l2b, qksc, vsc, osc, f1sc, f2sc; };
+    // WH_PREC_FP8, encoder side: code values as a bf16 matrix + the row scales
+    auto put_q = [&](const float* W, size_t rows, size_t cols, size_t* sc_off) {
+        QRows q;
+        quantize_rows(W, rows, cols, 1.0f, q, 0, rows);
+        *sc_off = st.put_f32(q.scale.data(), rows);
+        return st.put_codes_bf16(q, rows, cols);
+    };
     std::vector<EncOff> eo(c.enc_layers);
     for (int i = 0; i < c.enc_layers; i++) {
         std::string p = e + ".layers." + std::to_string(i);
         EncOff& x = eo[i];
-        x.qk = st.reserve(2 * d * d * m->esz);
-        for (size_t r = 0; r < d; r++) {
-            st.put_row(x.qk, r, d, T(p + ".self_attn.q_proj.weight") + r * d, d, qs);
-            st.put_row(x.qk, d + r, d, T(p + ".self_attn.k_proj.weight") + r * d, d, 1.0f);
+        x.qksc = x.vsc = x.osc = x.f1sc = x.f2sc = NONE;
+        if (f8) {
+            QRows q;
+            quantize_rows(T(p + ".self_attn.q_proj.weight"), d, d, qs, q, 0, 2 * d);
+            quantize_rows(T(p + ".self_attn.k_proj.weight"), d, d, 1.0f, q, d, 2 * d);
+            x.qk = st.put_codes_bf16(q, 2 * d, d);
+            x.qksc = st.put_f32(q.scale.data(), 2 * d);
+        } else {
+            x.qk = st.reserve(2 * d * d * m->esz);
+            for (size_t r = 0; r < d; r++) {
+                st.put_row(x.qk, r, d, T(p + ".self_attn.q_proj.weight") + r * d, d, qs);
+                st.put_row(x.qk, d + r, d, T(p + ".self_attn.k_proj.weight") + r * d, d, 1.0f);
+            }
         }
         tmp.assign(2 * d, 0.0f);
         for (size_t r = 0; r < d; r++) tmp[r] = T(p + ".self_attn.q_proj.bias")[r] * qs;
         x.qkb = st.put_f32(tmp.data(), 2 * d);
-        x.v = st.put_mat(T(p + ".self_attn.v_proj.weight"), d, d, d);
+        x.v = f8 ? put_q(T(p + ".self_attn.v_proj.weight"), d, d, &x.vsc) : st.put_mat(T(p + ".self_attn.v_proj.weight"), d, d, d);
         x.vb = st.put_f32(T(p + ".self_attn.v_proj.bias"), d);
-        x.o = st.put_mat(T(p + ".self_attn.out_proj.weight"), d, d, d);
+        x.o = f8 ? put_q(T(p + ".self_attn.out_proj.weight"), d, d, &x.osc) : st.put_mat(T(p + ".self_attn.out_proj.weight"), d, d, d);
         x.ob = st.put_f32(T(p + ".self_attn.out_proj.bias"), d);
-        x.f1 = st.put_mat(T(p + ".fc1.weight"), F, d, d);
+        x.f1 = f8 ? put_q(T(p + ".fc1.weight"), F, d, &x.f1sc) : st.put_mat(T(p + ".fc1.weight"), F, d, d);
         x.f1b = st.put_f32(T(p + ".fc1.bias"), F);
-        x.f2 = st.put_mat(T(p + ".fc2.weight"), d, F, F);
+        x.f2 = f8 ? put_q(T(p + ".fc2.weight"), d, F, &x.f2sc) : st.put_mat(T(p + ".fc2.weight"), d, F, F);
         x.f2b = st.put_f32(T(p + ".fc2.bias"), d);
         x.l1w = st.put_f32(T(p + ".self_attn_layer_norm.weight"), d);
         x.l1b = st.put_f32(T(p + ".self_attn_layer_norm.bias"), d);
@@ -444,7 +518,27 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     size_t o_elnw = st.put_f32(T(e + ".layer_norm.weight"), d), o_elnb = st.put_f32(T(e + ".layer_norm.bias"), d);
     size_t o_tok = st.put_mat(T(dd + ".embed_tokens.weight"), c.vocab, d, d);
     size_t o_dpos = st.put_f32(T(dd + ".embed_positions.weight"), (size_t)c.n_text_ctx * d);
-    struct DecOff { size_t qkv, qkvb, qkvs, o, ob, cq, cqb, cqs, co, cob, f1, f1b, f1s, f2, f2b, l1w, l1b, l2w, l2b, l3w, l3b; };
+    struct DecOff { size_t qkv, qkvb, qkvs, o, ob, cq, cqb, cqs, co, cob, f1, f1b, f1s, f2, f2b, l1w, l1b, l2w, l2b, l3w, l3b,
+                           qkvsc, osc, cqsc, cosc, f1sc, f2sc; };
+    // WH_PREC_FP8, decoder side: raw e4m3 codes + row scales.  A LayerNorm consumer keeps γ on the activation side, so
+    // its constants are s[n] = sum_k γ[k] W[n][k] and c[n] = bias[n] + sum_k β[k] W[n][k] of the DEQUANTISED weights.
+    auto put_codes = [&](const QRows& q, size_t* sc_off) {
+        *sc_off = st.put_f32(q.scale.data(), q.scale.size());
+        return st.put_bytes(q.codes.data(), q.codes.size());
+    };
+    auto ln_consts_q = [&](const QRows& q, size_t row0, size_t rows, size_t cols, const float* gamma, const float* beta,
+                           const float* bias, float rscale, float* s_out, float* c_out) {
+        for (size_t r = 0; r < rows; r++) {
+            double sacc = 0.0, cacc = 0.0;
+            for (size_t k = 0; k < cols; k++) {
+                const double w = (double)wh_e4m3_to_f32(q.codes[(row0 + r) * cols + k]);
+                sacc += (double)gamma[k] * w;
+                cacc += (double)beta[k] * w;
+            }
+            s_out[r] = (float)(sacc * (double)q.scale[row0 + r]);
+            c_out[r] = (float)(cacc * (double)q.scale[row0 + r] + (bias ? (double)bias[r] * rscale : 0.0));
+        }
+    };
     // LayerNorm folded into the consumer GEMM: rows [row0, row0+rows) of the matrix at `off`
     // become W'[r][k] = rscale * W[r][k] * gamma[k] in the compute dtype; s[r] = sum_k W'[r][k] (of the values
     // as stored), c[r] = sum_k beta[k] * rscale * W[r][k] + rscale * bias[r]
@@ -469,12 +563,56 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     size_t o_ckv = st.reserve(Ld * 2 * d * d * m->esz);
     tmp.assign(Ld * 2 * d, 0.0f);
     std::vector<float> ckvb(Ld * 2 * d, 0.0f);
+    std::vector<float> ckvsc(Ld * 2 * d, 1.0f);
     for (int i = 0; i < c.dec_layers; i++) {
         std::string p = dd + ".layers." + std::to_string(i);
         DecOff& x = dof[i];
         const float *g1 = T(p + ".self_attn_layer_norm.weight"), *b1 = T(p + ".self_attn_layer_norm.bias");
-        x.qkv = st.reserve(3 * d * d * m->esz);
         std::vector<float> s3(3 * d), c3(3 * d), s1(std::max(d, F)), c1(std::max(d, F));
+        x.qkvsc = x.osc = x.cqsc = x.cosc = x.f1sc = x.f2sc = NONE;
+        if (f8) {
+            const float *g2 = T(p + ".encoder_attn_layer_norm.weight"), *b2 = T(p + ".encoder_attn_layer_norm.bias");
+            const float *g3 = T(p + ".final_layer_norm.weight"), *b3 = T(p + ".final_layer_norm.bias");
+            QRows q;
+            quantize_rows(T(p + ".self_attn.q_proj.weight"), d, d, qs, q, 0, 3 * d);
+            quantize_rows(T(p + ".self_attn.k_proj.weight"), d, d, 1.0f, q, d, 3 * d);
+            quantize_rows(T(p + ".self_attn.v_proj.weight"), d, d, 1.0f, q, 2 * d, 3 * d);
+            ln_consts_q(q, 0, d, d, g1, b1, T(p + ".self_attn.q_proj.bias"), qs, s3.data(), c3.data());
+            ln_consts_q(q, d, d, d, g1, b1, nullptr, 1.0f, s3.data() + d, c3.data() + d);
+            ln_consts_q(q, 2 * d, d, d, g1, b1, T(p + ".self_attn.v_proj.bias"), 1.0f, s3.data() + 2 * d, c3.data() + 2 * d);
+            x.qkv = put_codes(q, &x.qkvsc);
+            x.qkvb = st.put_f32(c3.data(), 3 * d);
+            x.qkvs = st.put_f32(s3.data(), 3 * d);
+            QRows qo; quantize_rows(T(p + ".self_attn.out_proj.weight"), d, d, 1.0f, qo, 0, d);
+            x.o = put_codes(qo, &x.osc);
+            QRows qc; quantize_rows(T(p + ".encoder_attn.q_proj.weight"), d, d, qs, qc, 0, d);
+            ln_consts_q(qc, 0, d, d, g2, b2, T(p + ".encoder_attn.q_proj.bias"), qs, s1.data(), c1.data());
+            x.cq = put_codes(qc, &x.cqsc);
+            x.cqb = st.put_f32(c1.data(), d);
+            x.cqs = st.put_f32(s1.data(), d);
+            QRows qco; quantize_rows(T(p + ".encoder_attn.out_proj.weight"), d, d, 1.0f, qco, 0, d);
+            x.co = put_codes(qco, &x.cosc);
+            QRows qk, qv;
+            quantize_rows(T(p + ".encoder_attn.k_proj.weight"), d, d, 1.0f, qk, 0, d);
+            quantize_rows(T(p + ".encoder_attn.v_proj.weight"), d, d, 1.0f, qv, 0, d);
+            for (size_t r = 0; r < d; r++) {
+                std::vector<float> rowk(d), rowv(d);
+                for (size_t k = 0; k < d; k++) { rowk[k] = wh_e4m3_to_f32(qk.codes[r * d + k]); rowv[k] = wh_e4m3_to_f32(qv.codes[r * d + k]); }
+                st.put_row(o_ckv, ((size_t)i * 2 + 0) * d + r, d, rowk.data(), d, 1.0f);
+                st.put_row(o_ckv, ((size_t)i * 2 + 1) * d + r, d, rowv.data(), d, 1.0f);
+                ckvsc[((size_t)i * 2 + 0) * d + r] = qk.scale[r];
+                ckvsc[((size_t)i * 2 + 1) * d + r] = qv.scale[r];
+                ckvb[((size_t)i * 2 + 1) * d + r] = T(p + ".encoder_attn.v_proj.bias")[r];
+            }
+            QRows q1; quantize_rows(T(p + ".fc1.weight"), F, d, 1.0f, q1, 0, F);
+            ln_consts_q(q1, 0, F, d, g3, b3, T(p + ".fc1.bias"), 1.0f, s1.data(), c1.data());
+            x.f1 = put_codes(q1, &x.f1sc);
+            x.f1b = st.put_f32(c1.data(), F);
+            x.f1s = st.put_f32(s1.data(), F);
+            QRows q2; quantize_rows(T(p + ".fc2.weight"), d, F, 1.0f, q2, 0, d);
+            x.f2 = put_codes(q2, &x.f2sc);
+        } else {
+        x.qkv = st.reserve(3 * d * d * m->esz);
         fold_ln(x.qkv, 0, T(p + ".self_attn.q_proj.weight"), d, d, qs, g1, b1, T(p + ".self_attn.q_proj.bias"), s3.data(), c3.data());
         fold_ln(x.qkv, d, T(p + ".self_attn.k_proj.weight"), d, d, 1.0f, g1, b1, nullptr, s3.data() + d, c3.data() + d);
         fold_ln(x.qkv, 2 * d, T(p + ".self_attn.v_proj.weight"), d, d, 1.0f, g1, b1, T(p + ".self_attn.v_proj.bias"), s3.data() + 2 * d,
@@ -482,14 +620,12 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
         x.qkvb = st.put_f32(c3.data(), 3 * d);
         x.qkvs = st.put_f32(s3.data(), 3 * d);
         x.o = st.put_mat(T(p + ".self_attn.out_proj.weight"), d, d, d);
-        x.ob = st.put_f32(T(p + ".self_attn.out_proj.bias"), d);
         x.cq = st.reserve(d * d * m->esz);
         fold_ln(x.cq, 0, T(p + ".encoder_attn.q_proj.weight"), d, d, qs, T(p + ".encoder_attn_layer_norm.weight"),
                 T(p + ".encoder_attn_layer_norm.bias"), T(p + ".encoder_attn.q_proj.bias"), s1.data(), c1.data());
         x.cqb = st.put_f32(c1.data(), d);
         x.cqs = st.put_f32(s1.data(), d);
         x.co = st.put_mat(T(p + ".encoder_attn.out_proj.weight"), d, d, d);
-        x.cob = st.put_f32(T(p + ".encoder_attn.out_proj.bias"), d);
         for (size_t r = 0; r < d; r++) {
             st.put_row(o_ckv, ((size_t)i * 2 + 0) * d + r, d, T(p + ".encoder_attn.k_proj.weight") + r * d, d, 1.0f);
             st.put_row(o_ckv, ((size_t)i * 2 + 1) * d + r, d, T(p + ".encoder_attn.v_proj.weight") + r * d, d, 1.0f);
@@ -501,6 +637,9 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
         x.f1b = st.put_f32(c1.data(), F);
         x.f1s = st.put_f32(s1.data(), F);
         x.f2 = st.put_mat(T(p + ".fc2.weight"), d, F, F);
+        }
+        x.ob = st.put_f32(T(p + ".self_attn.out_proj.bias"), d);
+        x.cob = st.put_f32(T(p + ".encoder_attn.out_proj.bias"), d);
         x.f2b = st.put_f32(T(p + ".fc2.bias"), d);
         x.l1w = st.put_f32(T(p + ".self_attn_layer_norm.weight"), d);
         x.l1b = st.put_f32(T(p + ".self_attn_layer_norm.bias"), d);
@@ -510,12 +649,29 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
         x.l3b = st.put_f32(T(p + ".final_layer_norm.bias"), d);
     }
     size_t o_ckvb = st.put_f32(ckvb.data(), ckvb.size());
+    size_t o_ckvsc = f8 ? st.put_f32(ckvsc.data(), ckvsc.size()) : NONE;
     size_t o_dlnw = st.put_f32(T(dd + ".layer_norm.weight"), d), o_dlnb = st.put_f32(T(dd + ".layer_norm.bias"), d);
     // LM head = tied embedding with the final LayerNorm folded in (a second copy: the plain one stays the lookup table)
-    size_t o_lmw = st.reserve((size_t)c.vocab * d * m->esz);
+    // (WH_PREC_FP8: γ sits on the activation side, so the lookup table itself is the operand)
     std::vector<float> lms(c.vocab), lmc(c.vocab);
-    fold_ln(o_lmw, 0, T(dd + ".embed_tokens.weight"), c.vocab, d, 1.0f, T(dd + ".layer_norm.weight"), T(dd + ".layer_norm.bias"), nullptr,
-            lms.data(), lmc.data());
+    size_t o_lmw = o_tok;
+    if (f8) {
+        const float *E = T(dd + ".embed_tokens.weight"), *gf = T(dd + ".layer_norm.weight"), *bfin = T(dd + ".layer_norm.bias");
+        for (size_t n = 0; n < (size_t)c.vocab; n++) {
+            double sacc = 0.0, cacc = 0.0;
+            for (size_t k = 0; k < d; k++) {
+                const double w = (double)bf16_to_f32(f32_to_bf16(E[n * d + k]));
+                sacc += (double)gf[k] * w;
+                cacc += (double)bfin[k] * w;
+            }
+            lms[n] = (float)sacc;
+            lmc[n] = (float)cacc;
+        }
+    } else {
+        o_lmw = st.reserve((size_t)c.vocab * d * m->esz);
+        fold_ln(o_lmw, 0, T(dd + ".embed_tokens.weight"), c.vocab, d, 1.0f, T(dd + ".layer_norm.weight"), T(dd + ".layer_norm.bias"), nullptr,
+                lms.data(), lmc.data());
+    }
     size_t o_lms = st.put_f32(lms.data(), c.vocab), o_lmc = st.put_f32(lmc.data(), c.vocab);
     // log-mel tables
     std::vector<double> tw;
@@ -549,6 +705,7 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
         EncOff& x = eo[i];
         m->enc[i] = EncLayerDev{P(x.qk), P(x.v), P(x.o), P(x.f1), P(x.f2), PF(x.qkb), PF(x.vb), PF(x.ob), PF(x.f1b),
                                 PF(x.f2b), PF(x.l1w), PF(x.l1b), PF(x.l2w), PF(x.l2b)};
+        if (f8) { m->enc[i].qk_sc = PF(x.qksc); m->enc[i].v_sc = PF(x.vsc); m->enc[i].o_sc = PF(x.osc); m->enc[i].fc1_sc = PF(x.f1sc); m->enc[i].fc2_sc = PF(x.f2sc); }
     }
     m->enc_ln_w = PF(o_elnw); m->enc_ln_b = PF(o_elnb);
     m->tok_emb = P(o_tok); m->dec_pos = PF(o_dpos);
@@ -558,8 +715,13 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
         m->dec[i] = DecLayerDev{P(x.qkv), P(x.o), P(x.cq), P(x.co), P(x.f1), P(x.f2), PF(x.qkvb), PF(x.ob), PF(x.cqb),
                                 PF(x.cob), PF(x.f1b), PF(x.f2b), PF(x.l1w), PF(x.l1b), PF(x.l2w), PF(x.l2b), PF(x.l3w),
                                 PF(x.l3b), PF(x.qkvs), PF(x.cqs), PF(x.f1s)};
+        if (f8) {
+            m->dec[i].qkv_sc = PF(x.qkvsc); m->dec[i].o_sc = PF(x.osc); m->dec[i].cq_sc = PF(x.cqsc);
+            m->dec[i].co_sc = PF(x.cosc); m->dec[i].fc1_sc = PF(x.f1sc); m->dec[i].fc2_sc = PF(x.f2sc);
+        }
     }
     m->cross_kv_w = P(o_ckv); m->cross_kv_b = PF(o_ckvb);
+    if (f8) m->cross_kv_sc = PF(o_ckvsc);
     m->dec_ln_w = PF(o_dlnw); m->dec_ln_b = PF(o_dlnb);
     m->lm_w = P(o_lmw); m->lm_s = PF(o_lms); m->lm_c = PF(o_lmc);
     m->mel_tw = (double*)P(o_tw); m->mel_win = PF(o_win); m->mel_fbT = PF(o_fb);

@@ -72,7 +72,7 @@ static bool parse_args(int argc, char** argv, Args& a) {
                    "[--task transcribe] [--max-new-tokens 128] [--warmup 0] [--limit-files 0] [--discovery-best-json F] "
                    "[--out-csv F] [--out-json F] [--out-summary-json F] [--intra-op N] [--inter-op N] [--write-txt] "
                    "[--tokenizer-json F] [--timestamps] [--chunk-parallelism N] [--chunk-length-s 30] [--overlap-s 5] "
-                   "[--device 0] [--precision bf16|f32] [--max-batch 16] [--synthetic-clips N] [--seed 1000]\n");
+                   "[--device 0] [--precision bf16|f32|fp8] [--max-batch 16] [--synthetic-clips N] [--seed 1000]\n");
             exit(0);
         } else {
             if (!need(i, argv[i], v, inl)) return false;
@@ -250,7 +250,7 @@ int main(int argc, char** argv) {
         if (!synthetic_model && !is_dir(a.onnx_dir)) throw std::runtime_error("onnx_dir does not exist or is not a directory: " + a.onnx_dir);
 
         wh_model* model = nullptr;
-        const int prec = a.precision == "f32" ? WH_PREC_F32 : WH_PREC_BF16;
+        const int prec = a.precision == "f32" ? WH_PREC_F32 : a.precision == "fp8" ? WH_PREC_FP8 : WH_PREC_BF16;
         if (int rc = wh_model_load(a.onnx_dir.c_str(), a.device, prec, &model))
             throw std::runtime_error("Failed to load " + a.onnx_dir + ": libwhisper_hip error " + std::to_string(rc) + ": " + wh_last_error(nullptr));
         wh_ctx* ctx = nullptr;

@@ -205,6 +205,61 @@ def iter_offsets(dims: WhisperDims) -> Iterator[Tuple[str, Tuple[int, ...], int]
 
 
 # ----------------------------------------------------------------------------------
+# fp8 weights: OCP e4m3fn, one f32 scale per output channel, for the Linear /
+# QKV weights only — the scope of the reference's weights-only MatMul/Gemm quantisation
+# (quantize_onnx_int8.py:37-42); convolutions, LayerNorms, biases and both embeddings stay as they are.
+# Bit-identical twins: wh_quantize_e4m3 / wh_dequantize_e4m3 in csrc/wh_model.cpp, orc_e4m3_* in oracle/.
+# ----------------------------------------------------------------------------------
+E4M3_MAX = 448.0
+
+
+def is_linear_weight(name: str) -> bool:
+    return name.endswith("_proj.weight") or name.endswith(".fc1.weight") or name.endswith(".fc2.weight")
+
+
+def quantize_e4m3(x: np.ndarray) -> np.ndarray:
+    """f32 -> e4m3fn code (uint8): round to nearest even, saturating at +-448, NaN -> 0x7F."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    sign = ((x.view(np.uint32) >> np.uint32(24)) & np.uint32(0x80)).astype(np.uint8)
+    a = np.minimum(np.abs(x), np.float32(E4M3_MAX))
+    u = a.view(np.uint32).astype(np.uint64)
+    r = u + np.uint64(0x7FFFF) + ((u >> np.uint64(20)) & np.uint64(1))          # RNE at mantissa bit 20
+    normal = (((r >> np.uint64(23)) - np.uint64(120)) << np.uint64(3)) | ((r >> np.uint64(20)) & np.uint64(7))
+    sub = np.rint(np.nan_to_num(a).astype(np.float64) * 512.0).astype(np.uint64)              # multiples of 2^-9; 8 = first normal
+    code = np.where(a >= np.float32(2.0 ** -6), np.minimum(normal, np.uint64(0x7E)), sub).astype(np.uint8)
+    code = np.where(np.isnan(x), np.uint8(0x7F), code)
+    return (code | sign).astype(np.uint8)
+
+
+def dequantize_e4m3(code: np.ndarray) -> np.ndarray:
+    c = np.asarray(code, dtype=np.uint8).astype(np.int32)
+    e, m = (c >> 3) & 15, c & 7
+    mag = np.where(e == 0, m * 2.0 ** -9, (8 + m) * np.exp2(e.astype(np.float64) - 10.0))
+    mag = np.where((c & 0x7F) == 0x7F, np.nan, mag)
+    return np.where(c & 0x80, -mag, mag).astype(np.float32)
+
+
+def quantize_linear(w: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """[N, K] f32 -> (codes uint8 [N, K], scale f32 [N]); scale[n] = max|w[n, :]| / 448 (1 for a zero row)."""
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    amax = np.max(np.abs(w), axis=1)
+    scale = np.where(amax > 0, amax / np.float32(E4M3_MAX), np.float32(1.0)).astype(np.float32)
+    return quantize_e4m3(w / scale[:, None]), scale
+
+
+def fake_quant_state_dict(sd: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """Every Linear weight replaced by dequant(quant(w)) in f32 — what an fp8-weight model computes with."""
+    out = {}
+    for name, w in sd.items():
+        if is_linear_weight(name):
+            q, s = quantize_linear(w)
+            out[name] = (dequantize_e4m3(q) * s[:, None]).astype(np.float32)
+        else:
+            out[name] = w
+    return out
+
+
+# ----------------------------------------------------------------------------------
 # synthetic audio (SURVEY.md §8d config 3)
 # ----------------------------------------------------------------------------------
 def synth_clip(index: int, base_seed: int = 1000, n: int = 480000) -> np.ndarray:
