@@ -53,3 +53,56 @@ def test_quantize_linear_rows():
     assert np.array_equal(fq["a.q_proj.weight"], deq.astype(np.float32))
     assert fq["a.q_proj.bias"] is w[0] or np.array_equal(fq["a.q_proj.bias"], w[0])
     assert np.array_equal(fq["x.embed_tokens.weight"], w)       # embeddings are not Linear weights
+
+
+def _write_nano_checkpoint(d, sd, dims):
+    import json
+    import struct
+    d.mkdir()
+    hdr, blobs, off = {}, [], 0
+    for name, arr in sd.items():
+        b = arr.astype("<f4").tobytes()
+        hdr[name] = {"dtype": "F32", "shape": list(arr.shape), "data_offsets": [off, off + len(b)]}
+        blobs.append(b)
+        off += len(b)
+    hj = json.dumps(hdr).encode()
+    (d / "model.safetensors").write_bytes(struct.pack("<Q", len(hj)) + hj + b"".join(blobs))
+    (d / "config.json").write_text(json.dumps({
+        "num_mel_bins": 80, "d_model": dims.d_model, "encoder_attention_heads": dims.n_heads, "decoder_attention_heads": dims.n_heads,
+        "encoder_layers": dims.enc_layers, "decoder_layers": dims.dec_layers, "encoder_ffn_dim": dims.ffn, "decoder_ffn_dim": dims.ffn,
+        "vocab_size": dims.vocab, "max_source_positions": 1500, "max_target_positions": 448}))
+    (d / "generation_config.json").write_text("{}")
+
+
+def test_quantize_fp8_tool(tmp_path):
+    """The offline converter (reference analogue: quantize_onnx_int8.py) rewrites only Linear weights, as e4m3 codes +
+    per-row scales that equal modelspec.quantize_linear, and carries the side files over."""
+    import subprocess
+    import sys
+    import os
+    from whisper_rust_ort_amd import quantize_fp8 as qt
+    dims = ms.PRESETS["nano"]
+    sd = ms.synth_state_dict(dims, 7)
+    src, dst = tmp_path / "src", tmp_path / "dst"
+    _write_nano_checkpoint(src, sd, dims)
+    tool = os.path.join(os.path.dirname(os.path.abspath(qt.__file__)), "quantize_fp8.py")
+    r = subprocess.run([sys.executable, tool, "--src_dir", str(src), "--dst_dir", str(dst)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.splitlines()[-2:] == ["DONE", f"Output dir: {dst}"]
+    assert (dst / "config.json").read_text() == (src / "config.json").read_text() and (dst / "generation_config.json").is_file()
+    out, meta = qt.read_safetensors(dst / "model.safetensors")
+    assert "e4m3" in meta["quantization"]
+    n_lin = 0
+    for name, arr in sd.items():
+        dtype, shape, data = out[name]
+        if ms.is_linear_weight(name):
+            n_lin += 1
+            q, s = ms.quantize_linear(arr)
+            assert dtype == "F8_E4M3" and shape == list(arr.shape) and data == q.tobytes()
+            sdt, sshape, sdata = out[name + "_scale"]
+            assert sdt == "F32" and sshape == [arr.shape[0]] and sdata == s.astype("<f4").tobytes()
+        else:
+            assert dtype == "F32" and data == arr.astype("<f4").tobytes() and (name + "_scale") not in out
+    assert n_lin == 6 * dims.enc_layers + 10 * dims.dec_layers
+    missing = subprocess.run([sys.executable, tool, "--src_dir", str(tmp_path / "nope"), "--dst_dir", str(dst)], capture_output=True, text=True)
+    assert missing.returncode != 0 and "Missing source dir" in missing.stderr

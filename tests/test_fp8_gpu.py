@@ -80,3 +80,31 @@ def test_fp8_batch_matches_single_and_is_deterministic(gpu):
     for i in (0, 3, 5):   # clips are independent units: each head's K/V scale is per clip
         assert ctx.transcribe_batch([clips[i]], params)[0].tolist() == a[i].tolist()
     assert all(len(t) == len(prompt) + 20 for t in a)
+
+
+def test_prequantised_checkpoint_equals_load_time_quantisation(gpu, tmp_path):
+    """quantize_fp8.py output loaded with precision fp8 uses the stored codes and scales: same tokens and logits as the
+    f32 checkpoint quantised at load time; loaded as bf16 it runs the dequantised weights (a valid, different model)."""
+    from whisper_rust_ort_amd import quantize_fp8 as qt
+    from test_fp8_cpu import _write_nano_checkpoint
+    dims = ms.PRESETS["nano"]
+    sd = ms.synth_state_dict(dims, 7)
+    src, dst = tmp_path / "src", tmp_path / "dst"
+    _write_nano_checkpoint(src, sd, dims)
+    qt.quantize_dir(src, dst)
+    pcm = ms.synth_clip(5)
+    prompt, eot = small_prompt(dims)
+    p = wb.DecodeParams(prompt, 16, eot, [eot])
+
+    def run(spec, prec):
+        ctx = wb.Context(wb.Model(spec, 0, prec), 1)
+        ctx.run_encoder(ctx.whisper_log_mel(pcm))
+        return ctx.greedy_decode_with_past(p, want_logits=True)
+
+    t_ref, l_ref = run("synthetic:nano:7", wb.WH_PREC_FP8)
+    t_src, l_src = run(str(src), wb.WH_PREC_FP8)
+    t_dst, l_dst = run(str(dst), wb.WH_PREC_FP8)
+    assert t_src.tolist() == t_ref.tolist() and np.array_equal(l_src, l_ref)
+    assert t_dst.tolist() == t_ref.tolist() and np.array_equal(l_dst, l_ref)
+    t_bf, _ = run(str(dst), wb.WH_PREC_BF16)
+    assert len(t_bf) == len(t_ref) and all(0 <= t < dims.vocab for t in t_bf.tolist())

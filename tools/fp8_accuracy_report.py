@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4] accuracy leg: fp8 (e4m3 weights + e4m3 cross-K/V) and bf16 against the exact-f32 mode of the same
+library (itself held to the CPU oracle within 1e-3 by tests/test_hip_parity.py) — token agreement of free-running
+greedy decodes and teacher-forced logit error, on whisper-base dims with the hash-seeded synthetic weights and the
+synthetic clips of the benchmark.  Writes one JSON object (stdout, or --out).
+
+    python tools/fp8_accuracy_report.py --clips 16 --forced-clips 4 --out gpurun_out/fp8_accuracy.json
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from whisper_rust_ort_amd import binding as wb  # noqa: E402
+from whisper_rust_ort_amd import modelspec as ms  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--preset", default="base")
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--clips", type=int, default=16)
+    ap.add_argument("--forced-clips", type=int, default=4)
+    ap.add_argument("--max-new-tokens", type=int, default=128)
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    dims = ms.PRESETS[a.preset]
+    prompt, eot = ([50258, 50259, 50359, 50363], 50257) if dims.vocab > 50400 else ([3, 5, 7, 9], 2)
+    clips = [ms.synth_clip(i) for i in range(a.clips)]
+    P, N = len(prompt), a.max_new_tokens
+    free, forced_logits, secs = {}, {}, {}
+    ref_tokens = None
+    for name in ("f32", "bf16", "fp8"):
+        model = wb.Model(f"synthetic:{a.preset}:{a.seed}", 0, wb.PRECISIONS[name])
+        ctx = wb.Context(model, a.clips)
+        params = wb.DecodeParams(prompt, N, eot, [eot])
+        ctx.transcribe_batch(clips, params)  # warm-up
+        t0 = time.perf_counter()
+        toks = ctx.transcribe_batch(clips, params)
+        secs[name] = time.perf_counter() - t0
+        free[name] = np.stack([t[P:] for t in toks])
+        if name == "f32":
+            ref_tokens = free[name]
+        one = wb.Context(model, 1)
+        fl = []
+        for i in range(a.forced_clips):   # teacher-forced on the f32 tokens: every mode scores the same prefixes
+            one.run_encoder(one.whisper_log_mel(clips[i]))
+            _, lg = one.greedy_decode_with_past(wb.DecodeParams(prompt, N, eot, [eot], forced=ref_tokens[i][:-1].tolist()), want_logits=True)
+            fl.append(lg)
+        forced_logits[name] = np.stack(fl)
+        del one, ctx, model
+        print(f"[fp8_accuracy] {name}: {a.clips} clips x {N} tokens in {secs[name]:.2f} s", file=sys.stderr, flush=True)
+
+    def free_stats(x, ref):
+        eq = x == ref
+        first = [int(np.argmin(r)) if not r.all() else len(r) for r in eq]
+        return {"token_agreement": float(eq.mean()), "clips_identical": int(sum(r.all() for r in eq)),
+                "mean_tokens_before_first_divergence": float(np.mean(first))}
+
+    def forced_stats(l, lref):
+        err = np.abs(l - lref)
+        top = np.argsort(-lref, axis=-1)[..., :32]
+        err_top = np.take_along_axis(err, top, axis=-1)
+        srt = np.sort(lref, axis=-1)
+        margin = srt[..., -1] - srt[..., -2]
+        am, amr = l.argmax(-1), lref.argmax(-1)
+        bound = 2.0 * err.max()
+        decided = margin > bound
+        return {"max_abs_logit_err": float(err.max()), "mean_abs_logit_err": float(err.mean()),
+                "max_abs_logit_err_top32": float(err_top.max()), "top1_agreement": float((am == amr).mean()),
+                "positions": int(am.size), "f32_top1_margin_median": float(np.median(margin)),
+                "positions_with_margin_above_2x_max_err": int(decided.sum()),
+                "top1_agreement_on_those": float((am == amr)[decided].mean()) if decided.any() else None}
+
+    logit_scale = float(np.abs(forced_logits["f32"]).mean())
+    out = {
+        "what": "BASELINE configs[4]: fp8 / bf16 vs exact-f32 accuracy, same library, same inputs",
+        "model": f"whisper-{a.preset} dims, hash-seeded synthetic weights (seed {a.seed}) — logits of random weights are nearly flat, "
+                 "so free-running agreement understates what trained weights give; the teacher-forced logit error is the transferable figure",
+        "clips": a.clips, "max_new_tokens": N, "forced_clips": a.forced_clips, "mean_abs_f32_logit": logit_scale,
+        "free_running_vs_f32": {k: free_stats(free[k], ref_tokens) for k in ("bf16", "fp8")},
+        "fp8_vs_bf16_free_running": free_stats(free["fp8"], free["bf16"]),
+        "teacher_forced_vs_f32": {k: forced_stats(forced_logits[k], forced_logits["f32"]) for k in ("bf16", "fp8")},
+        "fp8_vs_bf16_teacher_forced": forced_stats(forced_logits["fp8"], forced_logits["bf16"]),
+        "batch_seconds": secs,
+    }
+    s = json.dumps(out, indent=1)
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        open(a.out, "w").write(s + "\n")
+    print(s)
+
+
+if __name__ == "__main__":
+    main()

@@ -529,6 +529,7 @@ int wh_model_load(const char* spec, int device, int precision, wh_model** out) {
     std::string s(spec);
     wh_dims dims{};
     std::vector<float> master;
+    WhPreQuant pre;
     if (s.rfind("synthetic:", 0) == 0) {
         size_t c2 = s.find(':', 10);
         std::string preset = s.substr(10, c2 == std::string::npos ? std::string::npos : c2 - 10);
@@ -536,10 +537,10 @@ int wh_model_load(const char* spec, int device, int precision, wh_model** out) {
         if (!wh_preset_dims(preset, &dims)) { wh_set_error("unknown synthetic preset '%s'", preset.c_str()); return WH_ERR_ARG; }
         wh_synth_weights(dims, seed, master);
     } else {
-        int rc = wh_load_model_dir(s, &dims, master);
+        int rc = wh_load_model_dir(s, &dims, master, &pre);
         if (rc) return rc;
     }
-    return wh_model_build(dims, std::move(master), device, precision, out);
+    return wh_model_build(dims, std::move(master), device, precision, out, &pre);
 }
 
 int wh_model_create(const wh_dims* dims, const float* weights, size_t n, int device, int precision, wh_model** out) {

@@ -128,11 +128,21 @@ struct wh_ctx {
     int cross_splits = 1;
 };
 
+// Linear weights that arrived already quantised (F8_E4M3 + "<name>_scale" in model.safetensors, written by
+// quantize_fp8.py): keyed by the tensor's offset in the f32 master blob, which then holds dequant(code) * scale.
+// WH_PREC_FP8 uses these codes and scales as they are instead of quantising the master copy again.
+struct WhPreQuantEntry {
+    std::vector<uint8_t> codes;  // [rows][cols]
+    std::vector<float> scale;    // [rows]
+};
+typedef std::map<size_t, WhPreQuantEntry> WhPreQuant;
+
 // wh_model.cpp
-int wh_model_build(const wh_dims& dims, std::vector<float>&& master, int device, int precision, wh_model** out);
+int wh_model_build(const wh_dims& dims, std::vector<float>&& master, int device, int precision, wh_model** out,
+                   const WhPreQuant* pre = nullptr);
 void wh_synth_weights(const wh_dims& dims, uint64_t seed, std::vector<float>& out);
 void wh_tensor_table(const wh_dims& dims, std::vector<std::pair<std::string, std::vector<int64_t>>>& out);
 bool wh_preset_dims(const std::string& name, wh_dims* out);
 uint8_t wh_e4m3_from_f32(float x);
 float wh_e4m3_to_f32(uint8_t c);
-int wh_load_model_dir(const std::string& dir, wh_dims* dims, std::vector<float>& master);
+int wh_load_model_dir(const std::string& dir, wh_dims* dims, std::vector<float>& master, WhPreQuant* pre = nullptr);

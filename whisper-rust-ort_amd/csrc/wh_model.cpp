@@ -200,7 +200,7 @@ static float half_to_float(uint16_t h) {
     return f;
 }
 
-int wh_load_model_dir(const std::string& dir, wh_dims* dims, std::vector<float>& master) {
+int wh_load_model_dir(const std::string& dir, wh_dims* dims, std::vector<float>& master, WhPreQuant* pre) {
     std::string txt, err;
     if (!read_file(dir + "/config.json", txt)) {
         wh_set_error("onnx_dir does not hold a config.json: %s", dir.c_str());
@@ -285,7 +285,8 @@ int wh_load_model_dir(const std::string& dir, wh_dims* dims, std::vector<float>&
             return WH_ERR_BAD_SHAPE;
         }
         const int64_t b0 = offs->arr[0]->as_i64(), b1 = offs->arr[1]->as_i64();
-        const size_t esz = dt->str == "F32" ? 4 : (dt->str == "F16" || dt->str == "BF16") ? 2 : 0;
+        const bool is_f8 = dt->str == "F8_E4M3";
+        const size_t esz = dt->str == "F32" ? 4 : (dt->str == "F16" || dt->str == "BF16") ? 2 : is_f8 ? 1 : 0;
         if (!esz || (size_t)(b1 - b0) != n * esz) {
             fclose(f);
             wh_set_error("%s: tensor %s dtype %s unsupported or size mismatch", st.c_str(), e.first.c_str(), dt->str.c_str());
@@ -298,7 +299,34 @@ int wh_load_model_dir(const std::string& dir, wh_dims* dims, std::vector<float>&
             return WH_ERR_IO;
         }
         float* dst = master.data() + off;
-        if (esz == 4) memcpy(dst, buf.data(), n * 4);
+        if (is_f8) {
+            // e4m3 codes [rows][cols] + "<name>_scale" F32 [rows] (quantize_fp8.py): master gets dequant * scale
+            const size_t rows = (size_t)e.second[0], cols = n / rows;
+            const whjson::Value* se = h->get(e.first + "_scale");
+            if (!se && e.first.rfind("model.", 0) == 0) se = h->get(e.first.substr(6) + "_scale");
+            const whjson::Value* sdt = se ? se->get("dtype") : nullptr;
+            const whjson::Value* soffs = se ? se->get("data_offsets") : nullptr;
+            if (!se || !sdt || sdt->str != "F32" || !soffs || soffs->arr.size() != 2 ||
+                (size_t)(soffs->arr[1]->as_i64() - soffs->arr[0]->as_i64()) != rows * 4) {
+                fclose(f);
+                wh_set_error("%s: F8_E4M3 tensor %s needs an F32 companion %s_scale with one value per row", st.c_str(), e.first.c_str(), e.first.c_str());
+                return WH_ERR_IO;
+            }
+            std::vector<float> sc(rows);
+            if (fseek(f, (long)(8 + hlen + soffs->arr[0]->as_i64()), SEEK_SET) || fread(sc.data(), 4, rows, f) != rows) {
+                fclose(f);
+                wh_set_error("%s: short read for %s_scale", st.c_str(), e.first.c_str());
+                return WH_ERR_IO;
+            }
+            const uint8_t* codes = (const uint8_t*)buf.data();
+            for (size_t r = 0; r < rows; r++)
+                for (size_t k = 0; k < cols; k++) dst[r * cols + k] = wh_e4m3_to_f32(codes[r * cols + k]) * sc[r];
+            if (pre) {
+                WhPreQuantEntry& pq = (*pre)[off];
+                pq.codes.assign(codes, codes + n);
+                pq.scale = sc;
+            }
+        } else if (esz == 4) memcpy(dst, buf.data(), n * 4);
         else {
             const uint16_t* s16 = (const uint16_t*)buf.data();
             if (dt->str == "BF16")
@@ -412,7 +440,7 @@ struct Stager {
 };
 }  // namespace
 
-int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device, int precision, wh_model** out) {
+int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device, int precision, wh_model** out, const WhPreQuant* pre) {
     if (precision != WH_PREC_F32 && precision != WH_PREC_BF16 && precision != WH_PREC_FP8) {
         wh_set_error("unsupported precision %d", precision);
         return WH_ERR_UNSUPPORTED;
@@ -457,6 +485,19 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     std::vector<float> tmp;
     const bool f8 = precision == WH_PREC_FP8;
     const size_t NONE = (size_t)-1;
+    // rows of a Linear weight as codes + scales: taken from the checkpoint when it came quantised, else computed here
+    auto qrows = [&](const float* W, size_t rows, size_t cols, float rscale, QRows& q, size_t row0, size_t total_rows) {
+        if (pre) {
+            auto it = pre->find((size_t)(W - m->master.data()));
+            if (it != pre->end() && it->second.codes.size() == rows * cols) {
+                if (q.codes.size() != total_rows * cols) { q.codes.assign(total_rows * cols, 0); q.scale.assign(total_rows, 1.0f); }
+                memcpy(q.codes.data() + row0 * cols, it->second.codes.data(), rows * cols);
+                for (size_t r = 0; r < rows; r++) q.scale[row0 + r] = it->second.scale[r] * rscale;
+                return;
+            }
+        }
+        quantize_rows(W, rows, cols, rscale, q, row0, total_rows);
+    };
 
     // conv weights tap-major: Wr[o][k*Cin + c] = W[o][c][k]
     auto conv_reorder = [&](const float* w, size_t cout, size_t cin, size_t kpad) {
@@ -477,7 +518,7 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     // WH_PREC_FP8, encoder side: code values as a bf16 matrix + the row scales
     auto put_q = [&](const float* W, size_t rows, size_t cols, size_t* sc_off) {
         QRows q;
-        quantize_rows(W, rows, cols, 1.0f, q, 0, rows);
+        qrows(W, rows, cols, 1.0f, q, 0, rows);
         *sc_off = st.put_f32(q.scale.data(), rows);
         return st.put_codes_bf16(q, rows, cols);
     };
@@ -488,8 +529,8 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
         x.qksc = x.vsc = x.osc = x.f1sc = x.f2sc = NONE;
         if (f8) {
             QRows q;
-            quantize_rows(T(p + ".self_attn.q_proj.weight"), d, d, qs, q, 0, 2 * d);
-            quantize_rows(T(p + ".self_attn.k_proj.weight"), d, d, 1.0f, q, d, 2 * d);
+            qrows(T(p + ".self_attn.q_proj.weight"), d, d, qs, q, 0, 2 * d);
+            qrows(T(p + ".self_attn.k_proj.weight"), d, d, 1.0f, q, d, 2 * d);
             x.qk = st.put_codes_bf16(q, 2 * d, d);
             x.qksc = st.put_f32(q.scale.data(), 2 * d);
         } else {
@@ -574,27 +615,27 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
             const float *g2 = T(p + ".encoder_attn_layer_norm.weight"), *b2 = T(p + ".encoder_attn_layer_norm.bias");
             const float *g3 = T(p + ".final_layer_norm.weight"), *b3 = T(p + ".final_layer_norm.bias");
             QRows q;
-            quantize_rows(T(p + ".self_attn.q_proj.weight"), d, d, qs, q, 0, 3 * d);
-            quantize_rows(T(p + ".self_attn.k_proj.weight"), d, d, 1.0f, q, d, 3 * d);
-            quantize_rows(T(p + ".self_attn.v_proj.weight"), d, d, 1.0f, q, 2 * d, 3 * d);
+            qrows(T(p + ".self_attn.q_proj.weight"), d, d, qs, q, 0, 3 * d);
+            qrows(T(p + ".self_attn.k_proj.weight"), d, d, 1.0f, q, d, 3 * d);
+            qrows(T(p + ".self_attn.v_proj.weight"), d, d, 1.0f, q, 2 * d, 3 * d);
             ln_consts_q(q, 0, d, d, g1, b1, T(p + ".self_attn.q_proj.bias"), qs, s3.data(), c3.data());
             ln_consts_q(q, d, d, d, g1, b1, nullptr, 1.0f, s3.data() + d, c3.data() + d);
             ln_consts_q(q, 2 * d, d, d, g1, b1, T(p + ".self_attn.v_proj.bias"), 1.0f, s3.data() + 2 * d, c3.data() + 2 * d);
             x.qkv = put_codes(q, &x.qkvsc);
             x.qkvb = st.put_f32(c3.data(), 3 * d);
             x.qkvs = st.put_f32(s3.data(), 3 * d);
-            QRows qo; quantize_rows(T(p + ".self_attn.out_proj.weight"), d, d, 1.0f, qo, 0, d);
+            QRows qo; qrows(T(p + ".self_attn.out_proj.weight"), d, d, 1.0f, qo, 0, d);
             x.o = put_codes(qo, &x.osc);
-            QRows qc; quantize_rows(T(p + ".encoder_attn.q_proj.weight"), d, d, qs, qc, 0, d);
+            QRows qc; qrows(T(p + ".encoder_attn.q_proj.weight"), d, d, qs, qc, 0, d);
             ln_consts_q(qc, 0, d, d, g2, b2, T(p + ".encoder_attn.q_proj.bias"), qs, s1.data(), c1.data());
             x.cq = put_codes(qc, &x.cqsc);
             x.cqb = st.put_f32(c1.data(), d);
             x.cqs = st.put_f32(s1.data(), d);
-            QRows qco; quantize_rows(T(p + ".encoder_attn.out_proj.weight"), d, d, 1.0f, qco, 0, d);
+            QRows qco; qrows(T(p + ".encoder_attn.out_proj.weight"), d, d, 1.0f, qco, 0, d);
             x.co = put_codes(qco, &x.cosc);
             QRows qk, qv;
-            quantize_rows(T(p + ".encoder_attn.k_proj.weight"), d, d, 1.0f, qk, 0, d);
-            quantize_rows(T(p + ".encoder_attn.v_proj.weight"), d, d, 1.0f, qv, 0, d);
+            qrows(T(p + ".encoder_attn.k_proj.weight"), d, d, 1.0f, qk, 0, d);
+            qrows(T(p + ".encoder_attn.v_proj.weight"), d, d, 1.0f, qv, 0, d);
             for (size_t r = 0; r < d; r++) {
                 std::vector<float> rowk(d), rowv(d);
                 for (size_t k = 0; k < d; k++) { rowk[k] = wh_e4m3_to_f32(qk.codes[r * d + k]); rowv[k] = wh_e4m3_to_f32(qv.codes[r * d + k]); }
@@ -604,12 +645,12 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
                 ckvsc[((size_t)i * 2 + 1) * d + r] = qv.scale[r];
                 ckvb[((size_t)i * 2 + 1) * d + r] = T(p + ".encoder_attn.v_proj.bias")[r];
             }
-            QRows q1; quantize_rows(T(p + ".fc1.weight"), F, d, 1.0f, q1, 0, F);
+            QRows q1; qrows(T(p + ".fc1.weight"), F, d, 1.0f, q1, 0, F);
             ln_consts_q(q1, 0, F, d, g3, b3, T(p + ".fc1.bias"), 1.0f, s1.data(), c1.data());
             x.f1 = put_codes(q1, &x.f1sc);
             x.f1b = st.put_f32(c1.data(), F);
             x.f1s = st.put_f32(s1.data(), F);
-            QRows q2; quantize_rows(T(p + ".fc2.weight"), d, F, 1.0f, q2, 0, d);
+            QRows q2; qrows(T(p + ".fc2.weight"), d, F, 1.0f, q2, 0, d);
             x.f2 = put_codes(q2, &x.f2sc);
         } else {
         x.qkv = st.reserve(3 * d * d * m->esz);
