@@ -85,6 +85,19 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     for (int i = 0; i < W_CH; i++) *reinterpret_cast<u32x4*>(&Ws[w_dst[i]]) = w_reg[i];
     __syncthreads();
 
+    // per-column epilogue operands (bias, fp8 channel scale) fetched under the main loop
+    f32x4 pre_b[TN], pre_w[TN];
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = n0 + wc * (BN / 2) + j * 16 + fg * 4;
+        pre_b[j] = f32x4{0, 0, 0, 0};
+        pre_w[j] = f32x4{1, 1, 1, 1};
+        if (n < g.N && g.bias_mode == 1) {
+            if (g.bias) pre_b[j] = *reinterpret_cast<const f32x4*>(g.bias + n);
+            if (g.wscale) pre_w[j] = *reinterpret_cast<const f32x4*>(g.wscale + n);
+        }
+    }
+
     const int nk = g.K / BK;
     for (int kt = 0; kt < nk; kt++) {
         const T* Ac = As + (kt & 1) * BM * LDK;
@@ -137,19 +150,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
             if (n >= g.N) continue;
             const long nc = (long)(n / g.n_per) * g.c_ns + (n % g.n_per);
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (g.wscale) {  // fp8 weights: code-valued operand, the channel scale is applied here in f32
-                if (g.bias_mode == 2) { v[0] *= wm; v[1] *= wm; v[2] *= wm; v[3] *= wm; }
-                else {
-                    f32x4 w4 = *reinterpret_cast<const f32x4*>(g.wscale + n);
-                    v[0] *= w4[0]; v[1] *= w4[1]; v[2] *= w4[2]; v[3] *= w4[3];
-                }
-            }
-            if (g.bias && g.bias_mode == 1) {
-                f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
-                v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
-            } else {
-                v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm;
-            }
+            // fp8 weights: code-valued operand, the channel scale (1 otherwise) is applied here in f32; then the bias
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = v[e] * (pre_w[j][e] * wm) + (pre_b[j][e] + bm);
             if (g.act == 1) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
