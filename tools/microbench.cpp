@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
     const int prec = WH_PREC_BF16;
     // buffers (bf16 = 2 bytes); contents zero → finite everywhere
     void* W = dmalloc((size_t)V * d * 2); void* X = dmalloc((size_t)64 * F * 2); float* xres = (float*)dmalloc((size_t)64 * d * 4);
-    float* lnw = (float*)dmalloc(d * 4); float* lnb = (float*)dmalloc(d * 4); float* bias = (float*)dmalloc(F * 4 * 4);
+    float* lnw = (float*)dmalloc(d * 4); float* lnb = (float*)dmalloc(d * 4); float* bias = (float*)dmalloc((size_t)52000 * 4);
     void* C1 = dmalloc((size_t)64 * 3 * F * 4); int* pos = (int*)dmalloc(4);
     for (auto nk : std::vector<std::pair<int, int>>{{512, 512}, {1536, 512}, {2048, 512}, {512, 2048}}) {
         SkinnyArgs a; a.W = W; a.bias = bias; a.M = B; a.N = nk.first; a.K = nk.second; a.X = X; a.x_mpad = 64;
@@ -75,6 +75,15 @@ int main(int argc, char** argv) {
             double us = time_chain(s, 10, [&]() { wh_launch_gemm(s, prec, false, g); });
             printf("enc gemm M=%d N=%4d K=%4d : %.1f us  %.0f TF/s\n", M, nk.first, nk.second, us, 2.0 * M * nk.first * nk.second / us / 1e6);
         }
+    }
+    {   // the LM-head shape through the K-split weight-streaming GEMM (no argmax): what would that structure cost?
+        void* Cb = dmalloc((size_t)64 * 51872 * 2 + 4096);
+        for (int dm : {4, 2, 1}) {
+            SkinnyArgs a; a.W = W; a.bias = bias; a.M = B; a.N = V; a.K = d; a.X = X; a.x_mpad = 64; a.C = Cb; a.ldc = 51872;
+            wh_dbg_mt = dm;
+            printf("dec_gemm at the LM-head shape N=%d rows/wg=%d : %.2f us\n", V, dm * 16, time_chain(s, 50, [&]() { wh_launch_dec_gemm(s, prec, false, a); }));
+        }
+        wh_dbg_mt = 0;
     }
     {   // LM head
         SkinnyArgs a; a.W = W; a.X = X; a.x_mpad = 64; a.M = B; a.N = V; a.K = d; a.pos_p = pos; a.n_prompt = 1;
