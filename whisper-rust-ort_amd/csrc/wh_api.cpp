@@ -282,8 +282,9 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     // (c->lnpart); the GEMM that consumes LN(x) has γ folded into its weights and applies mean / rstd in
     // its epilogue (wh_model.cpp fold_ln).
     const int ln_tiles_d = (int)(d / 16);
-    auto launch_step = [&](bool emits) {
-        {   // token + position embedding → x, raw slab, row sums (one "tile")
+    // `embed_first`: this step embeds its own input token; false when the previous step's argmax finish already did
+    auto launch_step = [&](bool emits, bool embed_first) {
+        if (embed_first) {   // token + position embedding → x, raw slab, row sums (one "tile")
             Prof pr(c, WH_KG_DEC_OTHER);
             wh_launch_dec_embed(s, prec, m->tok_emb, m->dec_pos, c->feed, ld, c->pos, c->dx, c->dxs, c->lnpart, nb, (int)d, mpad,
                                 f8 ? m->dec[0].ln1_w : nullptr);
@@ -369,7 +370,13 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 a.logits = d_logits; a.logits_rows = (int)logits_rows; a.part_val = c->part_val; a.part_idx = c->part_idx;
                 wh_launch_lm_head(s, prec, a);
             }
-            { Prof pr(c, WH_KG_DEC_OTHER); wh_launch_argmax_finish(s, c->part_val, c->part_idx, n_tiles, c->pos, c->step_ticket, st, nb); }
+            {   // argmax finish + greedy bookkeeping + the next position's embedding
+                Prof pr(c, WH_KG_DEC_OTHER);
+                NextEmbed ne;
+                ne.tok_emb = m->tok_emb; ne.pos_emb = m->dec_pos; ne.x = c->dx; ne.xslab = c->dxs; ne.stats = c->lnpart;
+                ne.xgamma = f8 ? m->dec[0].ln1_w : nullptr; ne.d = (int)d; ne.mpad = mpad;
+                wh_launch_argmax_finish(s, prec, c->part_val, c->part_idx, n_tiles, c->pos, c->step_ticket, st, nb, ne);
+            }
         }
     };
     // Positions 0 .. P-1 (the prompt, the last of which emits the first token) are launched eagerly;
@@ -377,7 +384,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     // reads the position from device memory, so the graph is position-independent.  The host then
     // pays one graph launch per token instead of ~50 kernel launches (src/main.rs:793-826 is one ORT
     // Run per token in the reference).
-    for (int step = 0; step < std::min(P, total_pos); step++) launch_step(step >= P - 1);
+    for (int step = 0; step < std::min(P, total_pos); step++) launch_step(step >= P - 1, true);
     const int remaining = total_pos - P;
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
@@ -389,7 +396,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
         c->capturing = true;   // no event records inside the captured step
         hipError_t ce = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
         if (ce == hipSuccess) {
-            launch_step(true);
+            launch_step(true, false);
             ce = hipStreamEndCapture(s, &graph);
         }
         c->capturing = false;
@@ -406,7 +413,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 return fail(c, WH_ERR_HIP, "hipGraphLaunch failed: %s", hipGetErrorString(ge));
             }
         } else {
-            launch_step(true);
+            launch_step(true, false);
         }
         // EOT early-out (src/main.rs:781-783, 820-822): poll the done flags every 16 generated tokens
         const int gen = r + 1;

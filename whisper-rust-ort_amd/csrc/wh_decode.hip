@@ -480,9 +480,10 @@ __global__ __launch_bounds__(256) void k_lm_head(SkinnyArgs a) {
 
 // Final reduce of the per-tile argmax partials + greedy bookkeeping for one clip per workgroup:
 // records the generated token, EOT stop (src/main.rs:781-783, 820-822) and the next input token.
+template <typename T>
 __global__ __launch_bounds__(256) void k_argmax_finish(const float* __restrict__ part_val,
                                                        const int* __restrict__ part_idx, int n_tiles, int* pos_p,
-                                                       int* ticket, DecodeState st) {
+                                                       int* ticket, DecodeState st, NextEmbed ne) {
     __shared__ float sv[256];
     __shared__ int si[256];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -525,6 +526,35 @@ __global__ __launch_bounds__(256) void k_argmax_finish(const float* __restrict__
             else if (tok == st.eot) st.done[b] = 1;
         }
         if (pos + 1 < st.tok_ld) st.feed[b * st.tok_ld + pos + 1] = next;
+        si[0] = next;
+    }
+    if (ne.tok_emb) {
+        // token + position embedding of the next position for this clip's row (k_dec_embed's work, one launch
+        // and one kernel boundary per token saved): f32 residual row, slab copy, row sums
+        __syncthreads();
+        const int next = si[0];
+        __syncthreads();
+        const T* er = (const T*)ne.tok_emb + (long)next * ne.d;
+        const float* pr = ne.pos_emb + (long)(pos + 1) * ne.d;
+        float s1 = 0.0f, s2 = 0.0f;
+        for (int c = tid * 4; c < ne.d; c += 1024) {
+            const f32x4 p4 = *reinterpret_cast<const f32x4*>(pr + c);
+            const f32x4 v = {cvt_in<T>(er[c]) + p4[0], cvt_in<T>(er[c + 1]) + p4[1], cvt_in<T>(er[c + 2]) + p4[2], cvt_in<T>(er[c + 3]) + p4[3]};
+            *reinterpret_cast<f32x4*>(ne.x + (long)b * ne.d + c) = v;
+            f32x4 g = {1, 1, 1, 1};
+            if (ne.xgamma) g = *reinterpret_cast<const f32x4*>(ne.xgamma + c);
+            store4((T*)ne.xslab + slab_idx(b, c, ne.mpad), v[0] * g[0], v[1] * g[1], v[2] * g[2], v[3] * g[3]);
+            s1 += (v[0] + v[1]) + (v[2] + v[3]);
+            s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if ((tid & 63) == 0) { sv[tid >> 6] = s1; sv[4 + (tid >> 6)] = s2; }
+        __syncthreads();
+        if (tid == 0) {
+            ne.stats[2 * b] = (sv[0] + sv[1]) + (sv[2] + sv[3]);
+            ne.stats[2 * b + 1] = (sv[4] + sv[5]) + (sv[6] + sv[7]);
+        }
     }
     advance_if_last(ticket, pos_p, gridDim.x);
 }
@@ -890,9 +920,10 @@ void wh_launch_lm_head(hipStream_t s, int prec, const SkinnyArgs& a) {
     else launch_lm_head_t<bf16>(s, a);
 }
 
-void wh_launch_argmax_finish(hipStream_t s, const float* part_val, const int* part_idx, int n_tiles, int* pos_p,
-                             int* ticket, const DecodeState& st, int B) {
-    hipLaunchKernelGGL(k_argmax_finish, dim3(B), dim3(256), 0, s, part_val, part_idx, n_tiles, pos_p, ticket, st);
+void wh_launch_argmax_finish(hipStream_t s, int prec, const float* part_val, const int* part_idx, int n_tiles, int* pos_p,
+                             int* ticket, const DecodeState& st, int B, const NextEmbed& ne) {
+    if (prec == WH_PREC_F32) hipLaunchKernelGGL(k_argmax_finish<float>, dim3(B), dim3(256), 0, s, part_val, part_idx, n_tiles, pos_p, ticket, st, ne);
+    else hipLaunchKernelGGL(k_argmax_finish<bf16>, dim3(B), dim3(256), 0, s, part_val, part_idx, n_tiles, pos_p, ticket, st, ne);
 }
 
 void wh_launch_dec_self_attn(hipStream_t s, int prec, const void* qkv, void* kc, void* vc, void* out, const int* pos_p,

@@ -68,6 +68,17 @@ struct SkinnyArgs {
     int* part_idx = nullptr;
 };
 
+// embedding of the NEXT position fused into the argmax finish (tok_emb == nullptr: not fused)
+struct NextEmbed {
+    const void* tok_emb = nullptr;   // [vocab][d] compute dtype
+    const float* pos_emb = nullptr;  // [n_text_ctx][d]
+    float* x = nullptr;              // [B][d] f32 residual stream
+    void* xslab = nullptr;           // slab copy (compute dtype), scaled by xgamma when given
+    float* stats = nullptr;          // [mpad][2] {sum x, sum x^2}
+    const float* xgamma = nullptr;
+    int d = 0, mpad = 0;
+};
+
 struct DecodeState {
     int* feed = nullptr;        // [B][tok_ld] input token per position
     int* out_tokens = nullptr;  // [B][tok_ld] prompt ++ generated
@@ -101,8 +112,8 @@ void wh_launch_dec_gemm(hipStream_t s, int prec, bool out_f32, const SkinnyArgs&
 void wh_launch_dec_embed(hipStream_t s, int prec, const void* tok_emb, const float* pos_emb, const int* feed, int feed_ld,
                          const int* pos_p, float* x, void* xslab, float* stats, int rows, int d, int mpad, const float* xgamma);
 void wh_launch_lm_head(hipStream_t s, int prec, const SkinnyArgs& a);
-void wh_launch_argmax_finish(hipStream_t s, const float* part_val, const int* part_idx, int n_tiles, int* pos_p,
-                             int* ticket, const DecodeState& st, int B);
+void wh_launch_argmax_finish(hipStream_t s, int prec, const float* part_val, const int* part_idx, int n_tiles, int* pos_p,
+                             int* ticket, const DecodeState& st, int B, const NextEmbed& ne);
 void wh_launch_dec_self_attn(hipStream_t s, int prec, const void* qkv, void* kc, void* vc, void* out, const int* pos_p,
                              int d, int n_heads, int tc, int B, int mpad);
 void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void* ck, const void* cv, float* part,
