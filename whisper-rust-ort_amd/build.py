@@ -11,8 +11,11 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libwhisper_hip.so")
 SOURCES = ["wh_mel.hip", "wh_gemm.hip", "wh_attn.hip", "wh_decode.hip", "wh_fp8.hip", "wh_model.cpp", "wh_api.cpp"]
 HEADERS = ["wh_common.h", "wh_kernels.h", "wh_internal.h", "wh_json.h", "../../include/whisper_hip.h"]
+# -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx950's register file is unified).  With the default
+# heuristic the attention kernel kept its score and output tiles in AGPRs and spent 160 of ~400 VALU instructions
+# per key tile on v_accvgpr_read/write copies around the softmax.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-pthread", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
-         "-x", "hip"]
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-x", "hip"]
 
 
 def _stale(target: str, deps) -> bool:

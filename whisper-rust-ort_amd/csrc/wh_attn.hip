@@ -38,7 +38,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, const T* __restrict__ vT,
                                                   T* __restrict__ out, int S, int d, int ldv, int n_heads) {
     constexpr int HD = WH_HEAD_DIM, KV = 64, QB = 128;
-    constexpr int LD = HD + 16 / (int)sizeof(T);  // padded LDS row (elements): +16 B
+    constexpr int LD = HD + 16 / (int)sizeof(T);  // padded LDS row of the K tile (elements): +16 B, conflict-free for 16-B reads
+    // V^T tile: read 8 bytes per lane (bf16), 16 lanes per LDS cycle — rows 144 B apart put lanes fl and fl+8 on the
+    // same banks (2-way conflict on every read); 136-B rows spread the 16 lanes over all 32 banks.  Its staging
+    // stores are then 8-byte ones (rows are only 8-byte aligned).
+    constexpr int LDV = sizeof(T) == 2 ? HD + 4 : LD;
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int CPR = HD / EPC;                 // 16-B chunks per 64-element row
     constexpr int NCH = KV * CPR / 256;           // staging chunks per thread per operand: 2 (bf16) / 4 (f32)
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, cons
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* Ks = reinterpret_cast<T*>(smem_raw);       // [2][KV][LD]   rows = keys
-    T* Vs = Ks + 2 * KV * LD;                     // [2][HD][LD]   rows = features, columns = keys
+    T* Vs = Ks + 2 * KV * LD;                     // [2][HD][LDV]  rows = features, columns = keys
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fl = lane & 15, fg = lane >> 4;
@@ -113,7 +117,14 @@ __global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, cons
 #pragma unroll
         for (int i = 0; i < NCH; i++) {
             *reinterpret_cast<u32x4*>(&Ks[(buf * KV + st_row[i]) * LD + st_col[i]]) = kreg[i];
-            *reinterpret_cast<u32x4*>(&Vs[(buf * HD + st_row[i]) * LD + st_col[i]]) = vreg[i];
+            if constexpr (sizeof(T) == 2) {
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                u32x2* vd = reinterpret_cast<u32x2*>(&Vs[(buf * HD + st_row[i]) * LDV + st_col[i]]);
+                vd[0] = u32x2{vreg[i].x, vreg[i].y};
+                vd[1] = u32x2{vreg[i].z, vreg[i].w};
+            } else {
+                *reinterpret_cast<u32x4*>(&Vs[(buf * HD + st_row[i]) * LDV + st_col[i]]) = vreg[i];
+            }
         }
     };
     load_tile(0);
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, cons
         const int cur = it & 1, k0 = it * KV;
         if (it + 1 < nt) load_tile(k0 + KV);  // flies under this tile's MFMAs
         const T* Kc = Ks + cur * KV * LD;
-        const T* Vc = Vs + cur * HD * LD;
+        const T* Vc = Vs + cur * HD * LDV;
         // ---- S^T[key][q]: rows key = 16*t + 4*fg + r, column q = fl ------------------------------------
         f32x4 sc[2][4];
 #pragma unroll
@@ -139,35 +150,47 @@ __global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, cons
             }
         }
         // ---- online softmax, lane-local per query column -----------------------------------------------
+        // VALU budget (this loop is VALU-bound, not MFMA-bound: 32 MFMAs = 512 cycles per tile and wave): the key
+        // mask only on the tail tile, scores taken to the exp2 domain by one packed FMA per pair, packed f32 math
+        // for the rescale and the row sum, the cross-row max on v_permlane*_swap instead of the LDS crossbar.
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        constexpr float LOG2E = 1.44269504088896341f;
         frag_t pf[2][2];
+        const bool tail = k0 + KV > S;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            float mx = -INFINITY;
+            if (tail) {
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+                for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    if (k0 + t * 16 + 4 * fg + r >= S) sc[u][t][r] = -INFINITY;
-                    mx = fmaxf(mx, sc[u][t][r]);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    for (int r = 0; r < 4; r++)
+                        if (k0 + t * 16 + 4 * fg + r >= S) sc[u][t][r] = -INFINITY;
+            }
+            float mx = fmaxf(fmaxf(sc[u][0][0], sc[u][0][1]), fmaxf(sc[u][0][2], sc[u][0][3]));
+#pragma unroll
+            for (int t = 1; t < 4; t++) mx = fmaxf(mx, fmaxf(fmaxf(sc[u][t][0], sc[u][t][1]), fmaxf(sc[u][t][2], sc[u][t][3])));
+            mx = xrow_max(mx);
             const float mn = fmaxf(mrow[u], mx);
-            const float alpha = __expf(mrow[u] - mn);
-            float rs = 0.0f;
+            const float alpha = __builtin_amdgcn_exp2f((mrow[u] - mn) * LOG2E);
+            const float nm2 = -mn * LOG2E;
+            f32x2 rs2 = {0.0f, 0.0f};
 #pragma unroll
             for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float p = __expf(sc[u][t][r] - mn);
-                    sc[u][t][r] = p;
-                    rs += p;
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2 e = f32x2{sc[u][t][r], sc[u][t][r + 1]} * f32x2{LOG2E, LOG2E} + f32x2{nm2, nm2};  // v_pk_fma_f32
+                    const f32x2 p = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+                    sc[u][t][r] = p.x;
+                    sc[u][t][r + 1] = p.y;
+                    rs2 += p;
                 }
-            lsum[u] = lsum[u] * alpha + rs;  // this lane group's share; the four groups are added at the end
+            lsum[u] = lsum[u] * alpha + (rs2.x + rs2.y);  // this lane group's share; the four groups are added at the end
             mrow[u] = mn;
+            const f32x2 a2 = {alpha, alpha};
 #pragma unroll
             for (int te = 0; te < 4; te++) {
-                o[u][te][0] *= alpha; o[u][te][1] *= alpha; o[u][te][2] *= alpha; o[u][te][3] *= alpha;
+                const f32x2 lo = f32x2{o[u][te][0], o[u][te][1]} * a2, hi = f32x2{o[u][te][2], o[u][te][3]} * a2;  // v_pk_mul_f32
+                o[u][te] = f32x4{lo.x, lo.y, hi.x, hi.y};
             }
             // P^T column operands: k-slot 8*fg + j ↔ key 16*t0 + 4*fg + j (j < 4), 16*t1 + 4*fg + j - 4 (j >= 4)
             pack_p(pf[u][0], sc[u][0], sc[u][1]);
@@ -178,7 +201,7 @@ __global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, cons
         for (int te = 0; te < 4; te++) {
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
-                const T* vp = &Vc[(te * 16 + fl) * LD + 32 * ks + 4 * fg];
+                const T* vp = &Vc[(te * 16 + fl) * LDV + 32 * ks + 4 * fg];
                 const frag_t vf = join_half(*reinterpret_cast<const half_t*>(vp), *reinterpret_cast<const half_t*>(vp + 16));
                 mma16(o[0][te], vf, pf[0][ks]);
                 mma16(o[1][te], vf, pf[1][ks]);
@@ -190,9 +213,7 @@ __global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, cons
     T* oc = out + clip * (long)S * d;
 #pragma unroll
     for (int u = 0; u < 2; u++) {
-        float l = lsum[u];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        const float l = xrow_sum(lsum[u]);
         const int q = q0 + 16 * u + fl;
         if (q >= S) continue;
         const float inv = 1.0f / l;

@@ -120,6 +120,23 @@ __device__ __forceinline__ float dpp_wave_max(float v) {
                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48))));
 }
 
+// All-reduce over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) without the LDS crossbar:
+// v_permlane16_swap (x, x) -> {[r0 r0 r2 r2], [r1 r1 r3 r3]}, v_permlane32_swap (x, x) -> {[r0 r1 r0 r1], [r2 r3 r2 r3]}
+// (gfx950; semantics checked in tools/permlane_check.hip).  `__shfl_xor(v, 16)` lowers to ds_bpermute + a wait.
+typedef __attribute__((ext_vector_type(2))) unsigned wh_u32x2;
+__device__ __forceinline__ float xrow_max(float v) {
+    wh_u32x2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(t.x), __uint_as_float(t.y));
+    t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(t.x), __uint_as_float(t.y));
+}
+__device__ __forceinline__ float xrow_sum(float v) {
+    wh_u32x2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(t.x) + __uint_as_float(t.y);
+    t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(t.x) + __uint_as_float(t.y);
+}
+
 typedef __attribute__((ext_vector_type(4))) unsigned wh_u32x4;
 // NOTE: hipcc (ROCm 7.2) miscompiles __builtin_bit_cast(bf16x2, <element of a uint vector>) — every
 // element resolves to element 0.  Going through memcpy produces the intended register moves.
