@@ -18,6 +18,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-pthread", "-Wa
          "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-x", "hip"]
 
 
+# wh_attn.hip: the softmax maxima never see a NaN that matters (a NaN score poisons its row either way); without
+# this every fmaxf operand is canonicalised first (v_max_f32 x, x, x), which doubles the max instructions of a loop
+# that is VALU-bound.  Infinities keep their meaning (-inf masks the tail keys).
+EXTRA_FLAGS = {"wh_attn.hip": ["-fno-honor-nans"]}
+
+
 def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
@@ -35,7 +41,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src + ".o")
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -18,6 +18,8 @@
 //   qk : [clip][S][2*d]      q at column h*64, k at column d + h*64           (QK projection output)
 //   vT : [clip][d][ldv]      row h*64+e holds V[:, e] over keys (key-contiguous, zero beyond S)
 //   out: [clip][S][d]        column h*64+e
+#include <type_traits>
+
 #include "wh_common.h"
 #include "wh_kernels.h"
 
@@ -131,9 +133,12 @@ __global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, cons
     store_tile(0);
     __syncthreads();
     const int nt = (S + KV - 1) / KV;
-    for (int it = 0; it < nt; it++) {
+    // One key tile.  LAST = the final tile: the only one that may hold keys >= S (masked) and the only one with no
+    // successor to stage — peeled so that the steady-state body carries neither the mask selects nor those branches.
+    auto tile_body = [&](int it, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;
         const int cur = it & 1, k0 = it * KV;
-        if (it + 1 < nt) load_tile(k0 + KV);  // flies under this tile's MFMAs
+        if (!LAST) load_tile(k0 + KV);  // flies under this tile's MFMAs
         const T* Kc = Ks + cur * KV * LD;
         const T* Vc = Vs + cur * HD * LDV;
         // ---- S^T[key][q]: rows key = 16*t + 4*fg + r, column q = fl ------------------------------------
@@ -156,10 +161,9 @@ __global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, cons
         typedef __attribute__((ext_vector_type(2))) float f32x2;
         constexpr float LOG2E = 1.44269504088896341f;
         frag_t pf[2][2];
-        const bool tail = k0 + KV > S;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            if (tail) {
+            if (LAST) {
 #pragma unroll
                 for (int t = 0; t < 4; t++)
 #pragma unroll
@@ -207,9 +211,13 @@ __global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, cons
                 mma16(o[1][te], vf, pf[1][ks]);
             }
         }
-        if (it + 1 < nt) store_tile(cur ^ 1);
-        __syncthreads();
-    }
+        if (!LAST) {
+            store_tile(cur ^ 1);
+            __syncthreads();
+        }
+    };
+    for (int it = 0; it + 1 < nt; it++) tile_body(it, std::false_type{});
+    tile_body(nt - 1, std::true_type{});
     T* oc = out + clip * (long)S * d;
 #pragma unroll
     for (int u = 0; u < 2; u++) {
