@@ -453,11 +453,22 @@ __global__ __launch_bounds__(256) void k_lm_head(SkinnyArgs a) {
                     if (!sup && v > bv) { bv = v; bi = nn; }  // strict >, NaN never wins
                 }
             }
-#pragma unroll
-            for (int off = 16; off < 64; off <<= 1) {
-                float ov = __shfl_xor(bv, off);
-                int oi = __shfl_xor(bi, off);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            // argmax over the four lane groups of this row on v_permlane*_swap (no LDS crossbar round trips)
+            {
+                wh_u32x2 tv = __builtin_amdgcn_permlane16_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+                wh_u32x2 ti = __builtin_amdgcn_permlane16_swap((unsigned)bi, (unsigned)bi, false, false);
+                float v0 = __uint_as_float(tv.x), v1 = __uint_as_float(tv.y);
+                int i0 = (int)ti.x, i1 = (int)ti.y;
+                bool take1 = v1 > v0 || (v1 == v0 && i1 < i0);
+                bv = take1 ? v1 : v0;
+                bi = take1 ? i1 : i0;
+                tv = __builtin_amdgcn_permlane32_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+                ti = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
+                v0 = __uint_as_float(tv.x); v1 = __uint_as_float(tv.y);
+                i0 = (int)ti.x; i1 = (int)ti.y;
+                take1 = v1 > v0 || (v1 == v0 && i1 < i0);
+                bv = take1 ? v1 : v0;
+                bi = take1 ? i1 : i0;
             }
             if (fg == 0 && m < a.M) {
                 a.part_val[(long)m * n_tiles + tile] = bv;
