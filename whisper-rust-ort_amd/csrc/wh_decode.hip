@@ -598,6 +598,12 @@ __global__ __launch_bounds__(64) void k_dec_self_attn(const T* __restrict__ qkv,
             for (int e = 0; e < HD / 8; e++) kr[i][e] = load_frag<T>(kcb + (long)j * HD + e * 8);
         }
     }
+    // ... and so do the first VPRE cached V rows (lane e reads column e): P·V then starts without a memory round
+    // trip, and what is left is fetched VPRE rows at a time (the loop used to pay one round trip per 8 rows)
+    constexpr int VPRE = 32;
+    T vpre[VPRE];
+#pragma unroll
+    for (int u = 0; u < VPRE; u++) vpre[u] = vcb[(long)min(u, tc - 1) * HD + lane];  // unconditional: rows >= pos are masked below
     const T kcur = row[d + h * HD + lane], vcur = row[2 * d + h * HD + lane];
     qs[lane] = cvt_in<T>(row[h * HD + lane]);
     kcb[(long)pos * HD + lane] = kcur;
@@ -642,15 +648,29 @@ __global__ __launch_bounds__(64) void k_dec_self_attn(const T* __restrict__ qkv,
     __syncthreads();
     // 3. P·V: eight cached rows in flight at a time; probabilities are LDS broadcasts
     float o = pcur * cvt_in<T>(vcur);
-    int j = 0;
-    for (; j + 8 <= pos; j += 8) {
+#pragma unroll
+    for (int u = 0; u < VPRE; u++) {
+        const float t = sc[u] * cvt_in<T>(vpre[u]);
+        o += (u < pos) ? t : 0.0f;  // select, not a branch (and never garbage * 0)
+    }
+    int j = VPRE;
+    for (; j + VPRE <= pos; j += VPRE) {
+        T v[VPRE];
+#pragma unroll
+        for (int u = 0; u < VPRE; u++) v[u] = vcb[(long)(j + u) * HD + lane];
+#pragma unroll
+        for (int u = 0; u < VPRE; u++) o += sc[j + u] * cvt_in<T>(v[u]);
+    }
+    for (; j < pos; j += 8) {  // tail groups: clamped rows, masked products — never a one-row-per-round-trip loop
         T v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = vcb[(long)(j + u) * HD + lane];
+        for (int u = 0; u < 8; u++) v[u] = vcb[(long)min(j + u, tc - 1) * HD + lane];
 #pragma unroll
-        for (int u = 0; u < 8; u++) o += sc[j + u] * cvt_in<T>(v[u]);
+        for (int u = 0; u < 8; u++) {
+            const float t = sc[min(j + u, 511)] * cvt_in<T>(v[u]);
+            o += (j + u < pos) ? t : 0.0f;
+        }
     }
-    for (; j < pos; j++) o += sc[j] * cvt_in<T>(vcb[(long)j * HD + lane]);
     out[slab_idx(b, h * HD + lane, mpad)] = cvt_out<T>(o / sum);
 }
 
