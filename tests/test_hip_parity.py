@@ -381,3 +381,21 @@ def test_launch_modes_agree(gpu):
     rem = steps - len(prompt)
     assert p_smp["dec_cross_attn"]["launches"] == n_layers * (len(prompt) + len([r for r in range(rem) if r % 4 == 2]))
     assert p_smp.get("dec_self_attn", {"launches": 0})["launches"] == 0 and p_smp["dec_cross_attn"]["ms"] > 0
+
+
+def test_base_bf16_256_clip_batch_matches_64_clip_batches(gpu):
+    """bench.py's default workload is one 256-clip device batch (one key range per clip in the cross attention, the
+    merged-operand out-projection at one partial per clip).  Clips are independent units, so the 256-clip batch must
+    reproduce the 64-clip batches row for row; 32 distinct clips are tiled 8x, so duplicates must agree as well."""
+    b256 = bundle("base", 1234, wb.WH_PREC_BF16, max_batch=256)
+    b64 = bundle("base", 1234, wb.WH_PREC_BF16, max_batch=64)
+    prompt, eot = small_prompt(b256.dims)
+    distinct = [ms.synth_clip(300 + i) for i in range(32)]
+    clips = [distinct[i % 32] for i in range(256)]
+    params = wb.DecodeParams(prompt, 48, eot, [eot])
+    full = [t.tolist() for t in b256.ctx.transcribe_batch(clips, params)]
+    assert all(len(t) == len(prompt) + 48 for t in full)
+    for i in range(32, 256):
+        assert full[i] == full[i % 32]
+    ref = [t.tolist() for t in b64.ctx.transcribe_batch(distinct, params)]
+    assert full[:32] == ref
