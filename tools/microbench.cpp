@@ -74,6 +74,18 @@ int main(int argc, char** argv) {
             g.M = M; g.N = nk.first; g.K = nk.second;
             double us = time_chain(s, 10, [&]() { wh_launch_gemm(s, prec, false, g); });
             printf("enc gemm M=%d N=%4d K=%4d : %.1f us  %.0f TF/s\n", M, nk.first, nk.second, us, 2.0 * M * nk.first * nk.second / us / 1e6);
+            if (nk.first == 2048) {
+                g.act = 1;
+                us = time_chain(s, 10, [&]() { wh_launch_gemm(s, prec, false, g); });
+                printf("enc gemm M=%d N=%4d K=%4d + GELU : %.1f us  %.0f TF/s\n", M, nk.first, nk.second, us, 2.0 * M * nk.first * nk.second / us / 1e6);
+                g.act = 0;
+            }
+            if (nk.first == 512) {
+                g.R = (const float*)Cc; g.ldr = 512; g.C = (char*)Cc + (size_t)M * 512 * 4; 
+                us = time_chain(s, 10, [&]() { wh_launch_gemm(s, prec, true, g); });
+                printf("enc gemm M=%d N=%4d K=%4d + f32 residual, f32 out : %.1f us  %.0f TF/s\n", M, nk.first, nk.second, us, 2.0 * M * nk.first * nk.second / us / 1e6);
+                g.R = nullptr; g.C = Cc;
+            }
         }
     }
     {   // the LM-head shape through the K-split weight-streaming GEMM (no argmax): what would that structure cost?
