@@ -292,6 +292,22 @@ def main() -> None:
                     "traffic": traffic, "kernel": "k_dec_cross_attn8" if prec == wb.WH_PREC_FP8 else "k_dec_cross_attn", "avg_launch_us": avg_s * 1e6,
                     "launches_timed": live["launches"], "alg_bytes_per_launch": work["cross_attn_bytes_per_launch"],
                     "share_of_kernel_time": breakdown["dec_cross_attn"]["ms"] / tot_ms}
+        d_, F_, T_, Le_ = dims.d_model, dims.ffn, dims.n_audio_ctx, dims.enc_layers
+        attn_flop = Le_ * 2 * 2 * T_ * T_ * d_ * a.clips
+        gemm_flop = work["enc_flop_per_clip"] * a.clips - attn_flop
+        mfma_peak = 2500.0 if prec != wb.WH_PREC_F32 else 2500.0 / 16.0   # TFLOP/s dense bf16; exact-f32 MFMA is 1/16 of it
+
+        def sec(bound, work_units, ms, peak, unit, note):
+            ach = work_units / (ms * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9) if ms > 0 else 0.0
+            return {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "ms_per_step": ms, "note": note}
+        secondary = {
+            "enc_attn": sec("mfma", attn_flop, breakdown["enc_attn"]["ms"], mfma_peak, "TFLOP/s",
+                            "k_enc_attn; VALU-bound below the MFMA roof (one v_exp_f32 per 256 MFMA flops at head_dim 64)"),
+            "enc_gemm": sec("mfma", gemm_flop, breakdown["enc_gemm"]["ms"], mfma_peak, "TFLOP/s",
+                            "k_gemm (Conv1d-as-GEMM, QK, V^T, out-proj, fc1, fc2); the group's time also holds the 13 encoder LayerNorm launches"),
+            "mel": sec("hbm", work["mel_bytes_per_clip"] * a.clips, breakdown["mel"]["ms"], HBM_PEAK_GBS, "GB/s",
+                       "k_mel_stft + k_mel_tokens; in practice f64-MFMA-issue bound (DFT on the f64 matrix cores)"),
+        }
         out = {
             "metric": "rtfx: audio seconds transcribed per wall second (whisper-base, 30 s clips, greedy 128 new tokens)",
             "value": audio_s / elapsed, "unit": "x real time", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -314,6 +330,9 @@ def main() -> None:
             "kernel_group_launches": {k: v["launches"] for k, v in breakdown.items()},
             "kernel_time_frac_of_step": tot_ms / ms_per_step,
             "roofline": roofline,
+            # the other kernel groups against their own roofs (event-timed in the untimed profiled pass; SURVEY §8d:
+            # MFMA utilisation of the encoder attention / GEMMs, HBM rate of the log-mel path)
+            "secondary_rooflines": secondary,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, a.seed, prompt, eot, a.max_new_tokens)
