@@ -872,6 +872,7 @@ void launch_dec_gemm_mt(hipStream_t s, const SkinnyArgs& a) {
     // batches beyond 64 rows (measured at 256 clips): 64-row groups for the 4-way K split — the row groups already give
     // hundreds of workgroups, and each weight fragment then feeds four MFMAs instead of one or two (-0.7 % step time)
     if (wh_dbg_mt <= 0 && a.M > 64 && NW == 4) mt_cap = 4;
+    if (wh_dbg_mt <= 0 && a.M > 64 && NW == 8 && !a.xpart) mt_cap = 2;  // fc2: 32-row groups (-0.5 %; 64 is slower again)
     const int mt = std::min(mt_cap, (a.M + 15) / 16);
     const size_t sm = (size_t)NW * mt * 64 * 16 + (size_t)4 * mt * 16 * 2 * 4;
     dim3 grid(n_tiles, (a.M + 16 * mt - 1) / (16 * mt));
