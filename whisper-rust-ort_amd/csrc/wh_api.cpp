@@ -326,16 +326,17 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 if (f8)
                     wh_launch_dec_cross_attn8(s, c->dq, (char*)c->cross_kv8 + (2 * l) * kv_stride, (char*)c->cross_kv8 + (2 * l + 1) * kv_stride,
                                               c->kv_amax + (long)(2 * l) * nb * D.n_heads, c->kv_amax + (long)(2 * l + 1) * nb * D.n_heads,
-                                              c->cpart, c->cml, (int)S, (int)d, D.n_heads, c->cross_splits, nb);
+                                              c->cpart, c->cml, (int)S, (int)d, D.n_heads, c->cross_splits, nb, c->datt, mpad);
                 else
                     wh_launch_dec_cross_attn(s, prec, c->dq, (char*)c->cross_kv + (2 * l) * kv_stride * esz,
                                              (char*)c->cross_kv + (2 * l + 1) * kv_stride * esz, c->cpart, c->cml,
-                                             (int)S, (int)d, D.n_heads, c->cross_splits, nb);
+                                             (int)S, (int)d, D.n_heads, c->cross_splits, nb, c->datt, mpad);
             }
             {   // merge of the key ranges ∘ cross-attention out-proj + residual → x, raw slab, LN3 partials
                 Prof pr(c, WH_KG_DEC_GEMM);
                 a = SkinnyArgs();
-                a.xpart = c->cpart; a.xml = c->cml; a.x_splits = c->cross_splits; a.x_heads = D.n_heads;
+                if (c->cross_splits == 1) a.X = c->datt;  // one key range per clip: the attention kernel wrote its output itself
+                else { a.xpart = c->cpart; a.xml = c->cml; a.x_splits = c->cross_splits; a.x_heads = D.n_heads; }
                 a.x_mpad = mpad; a.W = L.co_w; a.bias = L.co_b; a.wscale = L.co_sc; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
                 a.M = nb; a.N = (int)d; a.K = (int)d; a.xslab_out = c->dxs; a.stats_out = c->lnpart;
                 if (f8) a.xgamma = L.ln3_w;

@@ -688,7 +688,7 @@ template <typename T, int NCH, int UNROLL>  // NCH = ceil(d*sizeof(T)/16 / 64): 
 __global__ __launch_bounds__(256) void k_dec_cross_attn(const T* __restrict__ q, const T* __restrict__ ck,
                                                         const T* __restrict__ cv, float* __restrict__ part,
                                                         float* __restrict__ ml, int S, int d, int n_heads,
-                                                        int splits) {
+                                                        int splits, T* __restrict__ out, int mpad) {
     constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-B chunk: 8 (bf16) / 4 (f32)
     constexpr int LPH = WH_HEAD_DIM / EPC;     // lanes per head: 8 / 16
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -838,6 +838,10 @@ __global__ __launch_bounds__(256) void k_dec_cross_attn(const T* __restrict__ q,
             num += sc * wo[w * d + n];
             den += sc * wl[w * n_heads + h];
         }
+        if (out) {  // one key range per clip: this IS the attention output (slab layout, compute dtype)
+            out[slab_idx(b, n, mpad)] = cvt_out<T>(num / den);
+            continue;
+        }
         pp[n] = num;
         if ((n % WH_HEAD_DIM) == 0) {
             mp[h] = M;
@@ -971,11 +975,11 @@ void wh_launch_dec_self_attn(hipStream_t s, int prec, const void* qkv, void* kc,
 }
 
 void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void* ck, const void* cv, float* part,
-                              float* ml, int S, int d, int n_heads, int splits, int B) {
+                              float* ml, int S, int d, int n_heads, int splits, int B, void* out, int mpad) {
     dim3 grid(splits, B);
     const size_t sm = sizeof(float) * ((size_t)8 * n_heads + 4 * (size_t)d);
 #define WH_CA(T_, N_, U_) hipLaunchKernelGGL((k_dec_cross_attn<T_, N_, U_>), grid, dim3(256), sm, s, (const T_*)q, (const T_*)ck, \
-                                             (const T_*)cv, part, ml, S, d, n_heads, splits)
+                                             (const T_*)cv, part, ml, S, d, n_heads, splits, (T_*)(splits == 1 ? out : nullptr), mpad)
     if (prec == WH_PREC_F32) {
         const int nch = (d / 4 + 63) / 64;  // f32: 4 elements per chunk
         if (nch == 1) WH_CA(float, 1, 4);

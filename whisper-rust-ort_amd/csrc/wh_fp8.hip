@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_dec_cross_attn8(const bf16* __restrict_
                                                          const unsigned char* __restrict__ cv,
                                                          const float* __restrict__ amax_k, const float* __restrict__ amax_v,
                                                          float* __restrict__ part, float* __restrict__ ml, int S, int d,
-                                                         int n_heads, int splits) {
+                                                         int n_heads, int splits, bf16* __restrict__ out, int mpad) {
     static_assert(KPI == 1 || NCH == 1, "several keys per instruction only when a row fits a wave");
     constexpr int LPK = 64 / KPI;  // lanes per key row (KPI > 1)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -216,6 +216,10 @@ __global__ __launch_bounds__(256) void k_dec_cross_attn8(const bf16* __restrict_
             num += sc * wo[(long)w * d + n];
             den += sc * wl[w * n_heads + h];
         }
+        if (out) {  // one key range per clip: this IS the attention output (slab layout [d/32][mpad][32])
+            out[((long)(n >> 5) * mpad + b) * 32 + (n & 31)] = (bf16)(num * sv / den);
+            continue;
+        }
         pp[n] = num * sv;
         if ((n % WH_HEAD_DIM) == 0) {
             mp[h] = M;
@@ -226,10 +230,11 @@ __global__ __launch_bounds__(256) void k_dec_cross_attn8(const bf16* __restrict_
 
 template <int KPI, int NCH, int UNROLL>
 void launch_ca8(hipStream_t s, const void* q, const void* ck, const void* cv, const float* amax_k, const float* amax_v, float* part,
-                float* ml, int S, int d, int n_heads, int splits, int B) {
+                float* ml, int S, int d, int n_heads, int splits, int B, void* out, int mpad) {
     const size_t sm = sizeof(float) * ((size_t)2 * 4 * KPI * n_heads + (size_t)4 * KPI * d);
     hipLaunchKernelGGL((k_dec_cross_attn8<KPI, NCH, UNROLL>), dim3(splits, B), dim3(256), sm, s, (const bf16*)q,
-                       (const unsigned char*)ck, (const unsigned char*)cv, amax_k, amax_v, part, ml, S, d, n_heads, splits);
+                       (const unsigned char*)ck, (const unsigned char*)cv, amax_k, amax_v, part, ml, S, d, n_heads, splits,
+                       (bf16*)(splits == 1 ? out : nullptr), mpad);
 }
 
 }  // namespace
@@ -245,11 +250,12 @@ void wh_launch_kv_quant(hipStream_t s, const void* kv_bf16, unsigned* amax, void
 }
 
 void wh_launch_dec_cross_attn8(hipStream_t s, const void* q, const void* ck, const void* cv, const float* amax_k,
-                               const float* amax_v, float* part, float* ml, int S, int d, int n_heads, int splits, int B) {
+                               const float* amax_v, float* part, float* ml, int S, int d, int n_heads, int splits, int B, void* out,
+                               int mpad) {
     const int chunks = d / 16;
-    if (chunks == 32) launch_ca8<2, 1, 4>(s, q, ck, cv, amax_k, amax_v, part, ml, S, d, n_heads, splits, B);       // d = 512
-    else if (chunks == 16) launch_ca8<4, 1, 2>(s, q, ck, cv, amax_k, amax_v, part, ml, S, d, n_heads, splits, B);  // d = 256
-    else if (chunks == 8) launch_ca8<8, 1, 1>(s, q, ck, cv, amax_k, amax_v, part, ml, S, d, n_heads, splits, B);   // d = 128
-    else if (chunks <= 64) launch_ca8<1, 1, 4>(s, q, ck, cv, amax_k, amax_v, part, ml, S, d, n_heads, splits, B);  // d <= 1024
-    else launch_ca8<1, 2, 2>(s, q, ck, cv, amax_k, amax_v, part, ml, S, d, n_heads, splits, B);                    // d = 1280
+    if (chunks == 32) launch_ca8<2, 1, 4>(s, q, ck, cv, amax_k, amax_v, part, ml, S, d, n_heads, splits, B, out, mpad);       // d = 512
+    else if (chunks == 16) launch_ca8<4, 1, 2>(s, q, ck, cv, amax_k, amax_v, part, ml, S, d, n_heads, splits, B, out, mpad);  // d = 256
+    else if (chunks == 8) launch_ca8<8, 1, 1>(s, q, ck, cv, amax_k, amax_v, part, ml, S, d, n_heads, splits, B, out, mpad);   // d = 128
+    else if (chunks <= 64) launch_ca8<1, 1, 4>(s, q, ck, cv, amax_k, amax_v, part, ml, S, d, n_heads, splits, B, out, mpad);  // d <= 1024
+    else launch_ca8<1, 2, 2>(s, q, ck, cv, amax_k, amax_v, part, ml, S, d, n_heads, splits, B, out, mpad);                    // d = 1280
 }
