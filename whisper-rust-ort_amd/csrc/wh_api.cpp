@@ -271,7 +271,6 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     DecodeState st;
     st.feed = c->feed; st.out_tokens = c->out_tokens; st.n_out = c->n_out; st.done = c->done;
     st.forced = c->forced; st.n_forced = (int)p->n_forced; st.n_prompt = P; st.eot = (int)p->eot; st.tok_ld = ld;
-    const int n_tiles = (D.vocab + 15) / 16;
     const long cache_l = (long)nb * D.n_heads * D.n_text_ctx * WH_HEAD_DIM;  // elements per layer
     const int total_pos = P + NEW - 1;
     std::vector<int> done_h(nb);
@@ -283,6 +282,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     // its epilogue (wh_model.cpp fold_ln).
     const int ln_tiles_d = (int)(d / 16);
     // `embed_first`: this step embeds its own input token; false when the previous step's argmax finish already did
+    int lm_parts = 0;
     auto launch_step = [&](bool emits, bool embed_first) {
         if (embed_first) {   // token + position embedding → x, raw slab, row sums (one "tile")
             Prof pr(c, WH_KG_DEC_OTHER);
@@ -370,13 +370,14 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 a.pos_p = c->pos; a.n_prompt = P; a.mask_first = c->mask_first; a.mask_base = c->mask_base;
                 a.logits = d_logits; a.logits_rows = (int)logits_rows; a.part_val = c->part_val; a.part_idx = c->part_idx;
                 wh_launch_lm_head(s, prec, a);
+                lm_parts = wh_lm_head_parts(prec, a);
             }
             {   // argmax finish + greedy bookkeeping + the next position's embedding
                 Prof pr(c, WH_KG_DEC_OTHER);
                 NextEmbed ne;
                 ne.tok_emb = m->tok_emb; ne.pos_emb = m->dec_pos; ne.x = c->dx; ne.xslab = c->dxs; ne.stats = c->lnpart;
                 ne.xgamma = f8 ? m->dec[0].ln1_w : nullptr; ne.d = (int)d; ne.mpad = mpad;
-                wh_launch_argmax_finish(s, prec, c->part_val, c->part_idx, n_tiles, c->pos, c->step_ticket, st, nb, ne);
+                wh_launch_argmax_finish(s, prec, c->part_val, c->part_idx, lm_parts, mpad, c->pos, c->step_ticket, st, nb, ne);
             }
         }
     };
@@ -620,7 +621,7 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
     const size_t o_dxs = cv.take(MP * d * esz), o_lnp = cv.take((d / 16) * MP * 2 * 4);
     const size_t o_datt = cv.take(MP * d * esz), o_dq = cv.take(B * d * esz), o_dh = cv.take(MP * F * esz);
     const size_t o_cpart = cv.take(B * c->cross_splits * d * 4), o_cml = cv.take(B * c->cross_splits * H * 2 * 4);
-    const size_t o_pv = cv.take(B * n_tiles * 4), o_pi = cv.take(B * n_tiles * 4);
+    const size_t o_pv = cv.take(align_up(B, 16) * (n_tiles + 4) * 4), o_pi = cv.take(align_up(B, 16) * (n_tiles + 4) * 4);  // [part][mpad]
     const size_t o_feed = cv.take(B * c->tok_ld * 4), o_out = cv.take(B * c->tok_ld * 4);
     const size_t o_nout = cv.take(B * 4), o_done = cv.take(B * 4), o_forced = cv.take(TC * 4), o_pos = cv.take(4);
     const size_t o_stk = cv.take(4);

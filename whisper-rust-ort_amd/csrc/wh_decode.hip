@@ -403,6 +403,12 @@ __global__ __launch_bounds__(256) void k_lm_head(SkinnyArgs a) {
     typedef typename FragT<T>::type frag_t;
     frag_t wA[DEPTH], wB[DEPTH];
     f32x4 acc[MT];
+    // masked argmax, lane-local across ALL of this wave's tiles (they are visited in increasing column order, so
+    // strict > keeps the lowest index on ties): the cross-lane reduce and the partial store happen once per wave
+    float bvw[MT];
+    int biw[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++) { bvw[t] = -INFINITY; biw[t] = 0x7fffffff; }
     auto load_unit = [&](frag_t (&wq)[DEPTH], int u) {
         const int tile = first + (u / nchunk) * stride, c0 = (u % nchunk) * DEPTH;
         int nrow = tile * 16 + fl;
@@ -436,12 +442,12 @@ __global__ __launch_bounds__(256) void k_lm_head(SkinnyArgs a) {
             for (int e = 0; e < 4; e++)
                 if (n + e < a.N) { sv[e] = a.ln_s[n + e]; cv[e] = a.bias[n + e]; }
         }
+        unsigned mbits = 0;  // suppress bits of this lane's 4 columns (one mask word covers a 16-column tile)
+        if (n < a.N) mbits = mask[n >> 5] >> (n & 31);
 #pragma unroll
         for (int t = 0; t < MT; t++) {
             const int m = m0 + t * 16 + fl;
             const float mean = a.ln_part ? lnstat[2 * (t * 16 + fl)] : 0.0f, rstd = a.ln_part ? lnstat[2 * (t * 16 + fl) + 1] : 1.0f;
-            float bv = -INFINITY;
-            int bi = 0x7fffffff;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int nn = n + e;
@@ -449,30 +455,9 @@ __global__ __launch_bounds__(256) void k_lm_head(SkinnyArgs a) {
                 if (nn < a.N && m < a.M) {
                     if (a.logits && gen >= 0 && gen < a.logits_rows)
                         a.logits[((long)m * a.logits_rows + gen) * a.N + nn] = v;
-                    const bool sup = (mask[nn >> 5] >> (nn & 31)) & 1u;
-                    if (!sup && v > bv) { bv = v; bi = nn; }  // strict >, NaN never wins
+                    const bool sup = (mbits >> e) & 1u;
+                    if (!sup && v > bvw[t]) { bvw[t] = v; biw[t] = nn; }  // strict >, NaN never wins
                 }
-            }
-            // argmax over the four lane groups of this row on v_permlane*_swap (no LDS crossbar round trips)
-            {
-                wh_u32x2 tv = __builtin_amdgcn_permlane16_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
-                wh_u32x2 ti = __builtin_amdgcn_permlane16_swap((unsigned)bi, (unsigned)bi, false, false);
-                float v0 = __uint_as_float(tv.x), v1 = __uint_as_float(tv.y);
-                int i0 = (int)ti.x, i1 = (int)ti.y;
-                bool take1 = v1 > v0 || (v1 == v0 && i1 < i0);
-                bv = take1 ? v1 : v0;
-                bi = take1 ? i1 : i0;
-                tv = __builtin_amdgcn_permlane32_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
-                ti = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
-                v0 = __uint_as_float(tv.x); v1 = __uint_as_float(tv.y);
-                i0 = (int)ti.x; i1 = (int)ti.y;
-                take1 = v1 > v0 || (v1 == v0 && i1 < i0);
-                bv = take1 ? v1 : v0;
-                bi = take1 ? i1 : i0;
-            }
-            if (fg == 0 && m < a.M) {
-                a.part_val[(long)m * n_tiles + tile] = bv;
-                a.part_idx[(long)m * n_tiles + tile] = bi;
             }
         }
     };
@@ -487,13 +472,41 @@ __global__ __launch_bounds__(256) void k_lm_head(SkinnyArgs a) {
             compute_unit(wB, u + 1);
         }
     }
+    // one partial per (wave, row): argmax over the four lane groups of a row on v_permlane*_swap, then 16 consecutive
+    // rows leave as one 64-byte store — layout [part][x_mpad], part = blockIdx.x * 4 + wave (k_argmax_finish reads
+    // gridDim.x * 4 parts per row)
+    const int part = blockIdx.x * 4 + wave;
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+        float bv = bvw[t];
+        int bi = biw[t];
+        wh_u32x2 tv = __builtin_amdgcn_permlane16_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+        wh_u32x2 ti = __builtin_amdgcn_permlane16_swap((unsigned)bi, (unsigned)bi, false, false);
+        float v0 = __uint_as_float(tv.x), v1 = __uint_as_float(tv.y);
+        int i0 = (int)ti.x, i1 = (int)ti.y;
+        bool take1 = v1 > v0 || (v1 == v0 && i1 < i0);
+        bv = take1 ? v1 : v0;
+        bi = take1 ? i1 : i0;
+        tv = __builtin_amdgcn_permlane32_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+        ti = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
+        v0 = __uint_as_float(tv.x); v1 = __uint_as_float(tv.y);
+        i0 = (int)ti.x; i1 = (int)ti.y;
+        take1 = v1 > v0 || (v1 == v0 && i1 < i0);
+        bv = take1 ? v1 : v0;
+        bi = take1 ? i1 : i0;
+        const int m = m0 + t * 16 + fl;
+        if (fg == 0 && m < a.M) {
+            a.part_val[(long)part * a.x_mpad + m] = bv;
+            a.part_idx[(long)part * a.x_mpad + m] = bi;
+        }
+    }
 }
 
 // Final reduce of the per-tile argmax partials + greedy bookkeeping for one clip per workgroup:
 // records the generated token, EOT stop (src/main.rs:781-783, 820-822) and the next input token.
 template <typename T>
 __global__ __launch_bounds__(256) void k_argmax_finish(const float* __restrict__ part_val,
-                                                       const int* __restrict__ part_idx, int n_tiles, int* pos_p,
+                                                       const int* __restrict__ part_idx, int n_tiles, int mpad, int* pos_p,
                                                        int* ticket, DecodeState st, NextEmbed ne) {
     __shared__ float sv[256];
     __shared__ int si[256];
@@ -501,7 +514,7 @@ __global__ __launch_bounds__(256) void k_argmax_finish(const float* __restrict__
     const int pos = *pos_p;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i0 = tid; i0 < n_tiles; i0 += 256 * 8) {
+    for (int i0 = tid; i0 < n_tiles; i0 += 256 * 8) {   // n_tiles = number of partials per row, layout [part][mpad]
         float v[8];
         int ix[8];
 #pragma unroll
@@ -509,7 +522,7 @@ __global__ __launch_bounds__(256) void k_argmax_finish(const float* __restrict__
             const int i = i0 + u * 256;
             v[u] = -INFINITY;
             ix[u] = 0x7fffffff;
-            if (i < n_tiles) { v[u] = part_val[(long)b * n_tiles + i]; ix[u] = part_idx[(long)b * n_tiles + i]; }
+            if (i < n_tiles) { v[u] = part_val[(long)i * mpad + b]; ix[u] = part_idx[(long)i * mpad + b]; }
         }
 #pragma unroll
         for (int u = 0; u < 8; u++)
@@ -930,7 +943,7 @@ void wh_launch_dec_embed(hipStream_t s, int prec, const void* tok_emb, const flo
 }
 
 template <typename T>
-void launch_lm_head_t(hipStream_t s, const SkinnyArgs& a) {
+void launch_lm_head_t(hipStream_t s, const SkinnyArgs& a, int* n_parts_out = nullptr) {
     const int n_tiles = (a.N + 15) / 16;
     int mt = std::min(wh_dbg_lm_mt, (a.M + 15) / 16);
     auto lds = [&](int t) { return (size_t)t * 16 * a.K * sizeof(T) + (size_t)t * 16 * 2 * 4; };
@@ -938,6 +951,7 @@ void launch_lm_head_t(hipStream_t s, const SkinnyArgs& a) {
     const size_t sm = lds(mt);
     const int per_cu = std::max<int>(1, (int)(150 * 1024 / sm));
     dim3 grid(std::min((n_tiles + 3) / 4, 256 * std::min(per_cu, wh_dbg_lm_blocks_per_cu) / ((a.M + 16 * mt - 1) / (16 * mt))), (a.M + 16 * mt - 1) / (16 * mt));
+    if (n_parts_out) { *n_parts_out = (int)grid.x * 4; return; }  // query only: partials per row = waves per row group
 #define WH_LM(MT_)                                                \
     {                                                             \
         auto kfn = k_lm_head<T, MT_>;                             \
@@ -959,10 +973,18 @@ void wh_launch_lm_head(hipStream_t s, int prec, const SkinnyArgs& a) {
     else launch_lm_head_t<bf16>(s, a);
 }
 
-void wh_launch_argmax_finish(hipStream_t s, int prec, const float* part_val, const int* part_idx, int n_tiles, int* pos_p,
+// number of argmax partials per row the LM head writes for this shape (its layout is [part][x_mpad])
+int wh_lm_head_parts(int prec, const SkinnyArgs& a) {
+    int n = 0;
+    if (prec == WH_PREC_F32) launch_lm_head_t<float>(nullptr, a, &n);
+    else launch_lm_head_t<bf16>(nullptr, a, &n);
+    return n;
+}
+
+void wh_launch_argmax_finish(hipStream_t s, int prec, const float* part_val, const int* part_idx, int n_parts, int mpad, int* pos_p,
                              int* ticket, const DecodeState& st, int B, const NextEmbed& ne) {
-    if (prec == WH_PREC_F32) hipLaunchKernelGGL(k_argmax_finish<float>, dim3(B), dim3(256), 0, s, part_val, part_idx, n_tiles, pos_p, ticket, st, ne);
-    else hipLaunchKernelGGL(k_argmax_finish<bf16>, dim3(B), dim3(256), 0, s, part_val, part_idx, n_tiles, pos_p, ticket, st, ne);
+    if (prec == WH_PREC_F32) hipLaunchKernelGGL(k_argmax_finish<float>, dim3(B), dim3(256), 0, s, part_val, part_idx, n_parts, mpad, pos_p, ticket, st, ne);
+    else hipLaunchKernelGGL(k_argmax_finish<bf16>, dim3(B), dim3(256), 0, s, part_val, part_idx, n_parts, mpad, pos_p, ticket, st, ne);
 }
 
 void wh_launch_dec_self_attn(hipStream_t s, int prec, const void* qkv, void* kc, void* vc, void* out, const int* pos_p,

@@ -112,7 +112,8 @@ void wh_launch_dec_gemm(hipStream_t s, int prec, bool out_f32, const SkinnyArgs&
 void wh_launch_dec_embed(hipStream_t s, int prec, const void* tok_emb, const float* pos_emb, const int* feed, int feed_ld,
                          const int* pos_p, float* x, void* xslab, float* stats, int rows, int d, int mpad, const float* xgamma);
 void wh_launch_lm_head(hipStream_t s, int prec, const SkinnyArgs& a);
-void wh_launch_argmax_finish(hipStream_t s, int prec, const float* part_val, const int* part_idx, int n_tiles, int* pos_p,
+int wh_lm_head_parts(int prec, const SkinnyArgs& a);  // argmax partials per row written by wh_launch_lm_head, layout [part][x_mpad]
+void wh_launch_argmax_finish(hipStream_t s, int prec, const float* part_val, const int* part_idx, int n_parts, int mpad, int* pos_p,
                              int* ticket, const DecodeState& st, int B, const NextEmbed& ne);
 void wh_launch_dec_self_attn(hipStream_t s, int prec, const void* qkv, void* kc, void* vc, void* out, const int* pos_p,
                              int d, int n_heads, int tc, int B, int mpad);
