@@ -139,6 +139,30 @@ __device__ __forceinline__ f32x4 partials_merge(const SkinnyArgs& a, PartRaw<SP>
     return acc;
 }
 
+// Sum of the LayerNorm partials {sum x, sum x^2} of row `row` over tiles q, q + step, q + 2 step, ... < n_tiles,
+// eight 8-byte loads in flight at a time (clamped re-reads are masked): a run-time loop with one load per
+// iteration costs one memory round trip per tile.
+__device__ __forceinline__ void ln_partial_sum(const float* __restrict__ part, int n_tiles, int x_mpad, int row, int q, int step,
+                                               float& s1, float& s2) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    s1 = 0.0f;
+    s2 = 0.0f;
+    for (int t0 = q; t0 < n_tiles; t0 += 8 * step) {
+        f32x2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int tl = min(t0 + u * step, n_tiles - 1);
+            v[u] = *reinterpret_cast<const f32x2*>(part + ((long)tl * x_mpad + row) * 2);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const bool ok = t0 + u * step < n_tiles;
+            s1 += ok ? v[u].x : 0.0f;
+            s2 += ok ? v[u].y : 0.0f;
+        }
+    }
+}
+
 // Weight operand of one k-step.  Native dtype: 8 consecutive k per lane (one MFMA per load).  e4m3 codes: 8 per lane
 // (fp8x8_t, one MFMA) or 16 per lane (fp8x16_t: one 16-byte load feeds two MFMAs — half the load instructions for
 // the same bytes); codes are dequantised in registers with v_cvt_scalef32_pk_bf16_fp8 (byte j of the dword is
@@ -215,12 +239,8 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
         constexpr int ROWS = MT * 16;
         if (tid < 4 * ROWS) {
             const int r = tid % ROWS, q = tid / ROWS;
-            float s1 = 0.0f, s2 = 0.0f;
-            for (int tl = q; tl < a.ln_tiles; tl += 4) {
-                const float* pp = a.ln_part + ((long)tl * a.x_mpad + m0 + r) * 2;
-                s1 += pp[0];
-                s2 += pp[1];
-            }
+            float s1, s2;
+            ln_partial_sum(a.ln_part, a.ln_tiles, a.x_mpad, m0 + r, q, 4, s1, s2);
             lnred[(q * ROWS + r) * 2] = s1;
             lnred[(q * ROWS + r) * 2 + 1] = s2;
         }
@@ -378,16 +398,24 @@ __global__ __launch_bounds__(256) void k_lm_head(SkinnyArgs a) {
     }
     // final LayerNorm folded in: mean / rstd of this row group from the producer's per-tile partial sums
     float* lnstat = reinterpret_cast<float*>(smem_raw + (size_t)nslab * ROWS * 32 * sizeof(T));  // [ROWS][2]
-    if (a.ln_part && tid < ROWS) {
-        float s1 = 0.0f, s2 = 0.0f;
-        for (int tl = 0; tl < a.ln_tiles; tl++) {
-            const float* pp = a.ln_part + ((long)tl * a.x_mpad + m0 + tid) * 2;
-            s1 += pp[0];
-            s2 += pp[1];
+    if (a.ln_part) {
+        // all 256 threads: thread (row r, quarter q) sums every 4th tile, the four quarters meet through LDS
+        float* lnq = lnstat + 2 * ROWS;  // [4][ROWS][2]
+        if (tid < 4 * ROWS) {
+            const int r = tid % ROWS, q = tid / ROWS;
+            float s1, s2;
+            ln_partial_sum(a.ln_part, a.ln_tiles, a.x_mpad, m0 + r, q, 4, s1, s2);
+            lnq[(q * ROWS + r) * 2] = s1;
+            lnq[(q * ROWS + r) * 2 + 1] = s2;
         }
-        const float mean = s1 / (float)a.K;
-        lnstat[2 * tid] = mean;
-        lnstat[2 * tid + 1] = rsqrtf(fmaxf(s2 / (float)a.K - mean * mean, 0.0f) + 1e-5f);
+        __syncthreads();
+        if (tid < ROWS) {
+            const float s1 = (lnq[tid * 2] + lnq[(ROWS + tid) * 2]) + (lnq[(2 * ROWS + tid) * 2] + lnq[(3 * ROWS + tid) * 2]);
+            const float s2 = (lnq[tid * 2 + 1] + lnq[(ROWS + tid) * 2 + 1]) + (lnq[(2 * ROWS + tid) * 2 + 1] + lnq[(3 * ROWS + tid) * 2 + 1]);
+            const float mean = s1 / (float)a.K;
+            lnstat[2 * tid] = mean;
+            lnstat[2 * tid + 1] = rsqrtf(fmaxf(s2 / (float)a.K - mean * mean, 0.0f) + 1e-5f);
+        }
     }
     const int pos = *a.pos_p;
     const int gen = pos - (a.n_prompt - 1);  // index of the token this row generates
@@ -946,7 +974,7 @@ template <typename T>
 void launch_lm_head_t(hipStream_t s, const SkinnyArgs& a, int* n_parts_out = nullptr) {
     const int n_tiles = (a.N + 15) / 16;
     int mt = std::min(wh_dbg_lm_mt, (a.M + 15) / 16);
-    auto lds = [&](int t) { return (size_t)t * 16 * a.K * sizeof(T) + (size_t)t * 16 * 2 * 4; };
+    auto lds = [&](int t) { return (size_t)t * 16 * a.K * sizeof(T) + (size_t)t * 16 * 2 * 4 * 5; };  // X tile + LN stats (+ 4 quarter sums)
     while (mt > 1 && lds(mt) > 150 * 1024) mt--;
     const size_t sm = lds(mt);
     const int per_cu = std::max<int>(1, (int)(150 * 1024 / sm));
