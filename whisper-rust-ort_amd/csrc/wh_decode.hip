@@ -391,11 +391,24 @@ __global__ __launch_bounds__(256) void k_lm_head(SkinnyArgs a) {
     T* Xs = reinterpret_cast<T*>(smem_raw);
     constexpr int ROWS = MT * 16;
     const int nslab = a.K >> 5, cps = ROWS * 32 / EPC;  // 16-B chunks per slab of this row group
-    for (int c = tid; c < nslab * cps; c += 256) {
-        const int sl = c / cps, o = (c - sl * cps) * EPC;
-        *reinterpret_cast<u32x4*>(Xs + (long)sl * ROWS * 32 + o) =
-            *reinterpret_cast<const u32x4*>((const T*)a.X + ((long)sl * a.x_mpad + m0) * 32 + o);
-    }
+    // sixteen 16-byte loads in flight per thread, then the LDS stores (a load -> store loop costs a round trip per
+    // chunk); the first batch's stores wait until the first weight unit is in flight too (see below)
+    u32x4 xr[16];
+    int xo[16];
+    auto stage_load = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int c = min(c0 + i * 256, nslab * cps - 1), sl = c / cps, o = (c - sl * cps) * EPC;
+            xo[i] = sl * ROWS * 32 + o;
+            xr[i] = *reinterpret_cast<const u32x4*>((const T*)a.X + ((long)sl * a.x_mpad + m0) * 32 + o);
+        }
+    };
+    auto stage_store = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (c0 + i * 256 < nslab * cps) *reinterpret_cast<u32x4*>(Xs + xo[i]) = xr[i];
+    };
+    stage_load(tid);
     // final LayerNorm folded in: mean / rstd of this row group from the producer's per-tile partial sums
     float* lnstat = reinterpret_cast<float*>(smem_raw + (size_t)nslab * ROWS * 32 * sizeof(T));  // [ROWS][2]
     if (a.ln_part) {
@@ -490,6 +503,11 @@ __global__ __launch_bounds__(256) void k_lm_head(SkinnyArgs a) {
         }
     };
     if (units > 0) load_unit(wA, 0);   // in flight while the activation tile is staged
+    stage_store(tid);
+    for (int c0 = tid + 256 * 16; c0 < nslab * cps; c0 += 256 * 16) {  // K > 512
+        stage_load(c0);
+        stage_store(c0);
+    }
     __syncthreads();
     for (int u = 0; u < units; u += 2) {
         const bool hasB = u + 1 < units;

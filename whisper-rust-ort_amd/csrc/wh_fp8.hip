@@ -29,14 +29,20 @@ __global__ __launch_bounds__(256) void k_kv_absmax(const bf16* __restrict__ kv, 
     const int r0 = blockIdx.x * rows_per_wg, r1 = min(S, r0 + rows_per_wg);
     const int cpr = d >> 3;  // 16-byte chunks per row
     const bf16* base = kv + pb * (long)S * d;
-    for (int it = r0 * cpr + tid; it < r1 * cpr; it += 256) {
-        const int ch = it % cpr;
-        const wh_u32x4 u = *reinterpret_cast<const wh_u32x4*>(base + (long)it * 8);
-        // |bf16| as an integer compare: clear the sign bits, take the larger halfword
-        const unsigned a0 = u.x & 0x7FFF7FFFu, a1 = u.y & 0x7FFF7FFFu, a2 = u.z & 0x7FFF7FFFu, a3 = u.w & 0x7FFF7FFFu;
-        unsigned mx = max(max(a0 & 0xFFFFu, a0 >> 16), max(a1 & 0xFFFFu, a1 >> 16));
-        mx = max(mx, max(max(a2 & 0xFFFFu, a2 >> 16), max(a3 & 0xFFFFu, a3 >> 16)));
-        atomicMax(&hm[(ch * 8) / WH_HEAD_DIM], mx << 16);  // bf16 bits -> f32 bits
+    const int it1 = r1 * cpr;
+    for (int it0 = r0 * cpr + tid; it0 < it1; it0 += 256 * 8) {  // eight 16-byte loads in flight per thread
+        wh_u32x4 u[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) u[i] = *reinterpret_cast<const wh_u32x4*>(base + (long)min(it0 + i * 256, it1 - 1) * 8);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int it = min(it0 + i * 256, it1 - 1);  // a clamped re-read only repeats a value already counted
+            // |bf16| as an integer compare: clear the sign bits, take the larger halfword
+            const unsigned a0 = u[i].x & 0x7FFF7FFFu, a1 = u[i].y & 0x7FFF7FFFu, a2 = u[i].z & 0x7FFF7FFFu, a3 = u[i].w & 0x7FFF7FFFu;
+            unsigned mx = max(max(a0 & 0xFFFFu, a0 >> 16), max(a1 & 0xFFFFu, a1 >> 16));
+            mx = max(mx, max(max(a2 & 0xFFFFu, a2 >> 16), max(a3 & 0xFFFFu, a3 >> 16)));
+            atomicMax(&hm[((it % cpr) * 8) / WH_HEAD_DIM], mx << 16);  // bf16 bits -> f32 bits
+        }
     }
     __syncthreads();
     if (tid < n_heads && hm[tid]) atomicMax(amax + pb * n_heads + tid, hm[tid]);
