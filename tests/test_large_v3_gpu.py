@@ -48,3 +48,31 @@ def test_large_v3_bf16_runs_and_is_deterministic():
     assert [t.tolist() for t in a] == [t.tolist() for t in b]
     assert all(len(t) == 20 for t in a)
     print("large-v3 bf16 timings", ctx.timings())
+
+
+@pytest.mark.skipif(not os.environ.get("WH_TEST_LARGE"), reason="set WH_TEST_LARGE=1")
+def test_large_v3_fp8_runs_and_tracks_bf16():
+    """d_model 1280 exercises the general-geometry variants of the fp8 kernels (two chunks per lane in the e4m3 cross
+    attention, 8-code weight loads where a wave's K share is not a multiple of 64, 20 heads in the K/V scale tables)."""
+    prompt, eot = [50258, 50259, 50360, 50364], 50257
+    clips = [ms.synth_clip(20 + i) for i in range(3)]
+    p = wb.DecodeParams(prompt, 12, eot, [eot])
+    m8 = wb.Model("synthetic:large-v3:5", 0, wb.WH_PREC_FP8)
+    c8 = wb.Context(m8, 4)
+    a = c8.transcribe_batch(clips, p)
+    b = c8.transcribe_batch(clips, p)
+    assert [t.tolist() for t in a] == [t.tolist() for t in b]
+    assert all(len(t) == 16 for t in a)
+    assert c8.transcribe_batch([clips[1]], p)[0].tolist() == a[1].tolist()
+    # teacher-forced on the fp8 tokens: bf16 logits of the same prefixes stay close (weights differ by the e4m3 rounding only)
+    c8.run_encoder(c8.whisper_log_mel(clips[0]))
+    forced = a[0][4:-1].tolist()
+    _, l8 = c8.greedy_decode_with_past(wb.DecodeParams(prompt, 12, eot, [eot], forced=forced), want_logits=True)
+    del c8, m8
+    mb = wb.Model("synthetic:large-v3:5", 0, wb.WH_PREC_BF16)
+    cb = wb.Context(mb, 1)
+    cb.run_encoder(cb.whisper_log_mel(clips[0]))
+    _, lb = cb.greedy_decode_with_past(wb.DecodeParams(prompt, 12, eot, [eot], forced=forced), want_logits=True)
+    diff = np.abs(l8 - lb)
+    print("large-v3 fp8 vs bf16 teacher-forced: mean |dlogit|", diff.mean(), "max", diff.max(), "logit scale", np.abs(lb).mean())
+    assert np.isfinite(l8).all() and diff.mean() < 0.25 * np.abs(lb).mean()
