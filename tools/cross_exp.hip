@@ -193,6 +193,10 @@ int main(int argc, char** argv) {
         });                                                                                                                        \
         printf("NW=%d U=%d mode=%d splits=%2d : %.2f us (%.2f TB/s)\n", NW_, U_, MODE_, splits, us, 2.0 * S * d * 2 * B / us / 1e6); \
     }
+    if (B >= 128) {  // large batches: one or two key ranges per clip
+        RUN(4, 4, 0, 1) RUN(4, 4, 1, 1) RUN(4, 4, 2, 1) RUN(8, 4, 1, 1) RUN(8, 2, 1, 1) RUN(4, 8, 1, 1) RUN(8, 4, 2, 1) RUN(4, 4, 1, 2) RUN(4, 4, 2, 2) RUN(16, 2, 1, 1) RUN(16, 2, 2, 1)
+        return 0;
+    }
     for (int sp : {4, 8}) {
         if (sp == 4) { RUN(4, 4, 0, 4) RUN(4, 4, 1, 4) RUN(4, 4, 2, 4) RUN(8, 4, 0, 4) RUN(8, 4, 1, 4) RUN(8, 4, 2, 4) RUN(8, 2, 0, 4) RUN(8, 2, 2, 4) RUN(4, 8, 2, 4) }
         else { RUN(4, 4, 0, 8) RUN(4, 4, 1, 8) RUN(4, 4, 2, 8) RUN(8, 2, 0, 8) RUN(8, 2, 2, 8) }
