@@ -111,7 +111,7 @@ int main(int argc, char** argv) {
             wh_dbg_cross_unroll = un;
             float* part = (float*)dmalloc((size_t)B * 32 * d * 4); float* ml = (float*)dmalloc((size_t)B * 32 * H * 2 * 4);
             int l = 0;
-            double us = time_chain(s, 60, [&]() { wh_launch_dec_cross_attn(s, prec, q, (char*)kv + (size_t)(2 * l) * plane * 2, (char*)kv + (size_t)(2 * l + 1) * plane * 2, part, ml, S, d, H, splits, B, out, 64); l = (l + 1) % L; });
+            double us = time_chain(s, 60, [&]() { wh_launch_dec_cross_attn(s, prec, q, (char*)kv + (size_t)(2 * l) * plane * 2, (char*)kv + (size_t)(2 * l + 1) * plane * 2, part, ml, S, d, H, splits, B, out, 64, true); l = (l + 1) % L; });
             printf("cross_attn B=%d unroll=%d splits=%2d : %.2f us  (%.2f TB/s)\n", B, un, splits, us, 2.0 * S * d * 2 * B / us / 1e6);
         }
         void* qkv = dmalloc((size_t)64 * 3 * d * 4); void* kc = dmalloc((size_t)B * H * 448 * 64 * 2); void* vc = dmalloc((size_t)B * H * 448 * 64 * 2);

@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
     float* part = (float*)dmalloc((size_t)B * splits * d * 4); float* ml = (float*)dmalloc((size_t)B * splits * H * 2 * 4);
     int l = 0;
     const int nc = 60, ng = 480;
-    hipGraphExec_t gc = capture(sa, nc, [&]() { wh_launch_dec_cross_attn(sa, WH_PREC_BF16, q, (char*)kv + (size_t)(2 * l) * plane * 2, (char*)kv + (size_t)(2 * l + 1) * plane * 2, part, ml, S, d, H, splits, B, out, 64); l = (l + 1) % L; });
+    hipGraphExec_t gc = capture(sa, nc, [&]() { wh_launch_dec_cross_attn(sa, WH_PREC_BF16, q, (char*)kv + (size_t)(2 * l) * plane * 2, (char*)kv + (size_t)(2 * l + 1) * plane * 2, part, ml, S, d, H, splits, B, out, 64, true); l = (l + 1) % L; });
     void* W = dmalloc((size_t)2048 * 2048 * 2); void* X = dmalloc((size_t)64 * 2048 * 2); float* bias = (float*)dmalloc(2048 * 4 * 4); void* C1 = dmalloc((size_t)64 * 2048 * 4 * 3);
     SkinnyArgs a; a.W = W; a.bias = bias; a.M = B; a.N = 1536; a.K = 512; a.X = X; a.x_mpad = 64; a.C = C1; a.c_mpad = 64;
     hipGraphExec_t gg = capture(sb, ng, [&]() { wh_launch_dec_gemm(sb, WH_PREC_BF16, false, a); });

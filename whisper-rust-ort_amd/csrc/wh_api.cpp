@@ -250,6 +250,9 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     }
 
     const bool f8 = prec == WH_PREC_FP8;
+    // the cross K/V of all layers are re-read at every position: below ~half the 256 MiB Infinity Cache they are served
+    // from it; above, their stream only evicts the decode weights and activations — then they are loaded non-temporally
+    const bool kv_nt = (double)D.dec_layers * 2.0 * nb * S * d * (f8 ? 1 : (double)esz) > 128.0 * 1024 * 1024;
     // cross-attention K/V of every decoder layer, once per clip: present.{i}.encoder.{key,value}
     // of the step-0 decoder run (src/main.rs:771-787)
     const long kv_stride = (long)nb * S * d;  // elements between consecutive [nb][S][d] planes
@@ -326,11 +329,11 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 if (f8)
                     wh_launch_dec_cross_attn8(s, c->dq, (char*)c->cross_kv8 + (2 * l) * kv_stride, (char*)c->cross_kv8 + (2 * l + 1) * kv_stride,
                                               c->kv_amax + (long)(2 * l) * nb * D.n_heads, c->kv_amax + (long)(2 * l + 1) * nb * D.n_heads,
-                                              c->cpart, c->cml, (int)S, (int)d, D.n_heads, c->cross_splits, nb, c->datt, mpad);
+                                              c->cpart, c->cml, (int)S, (int)d, D.n_heads, c->cross_splits, nb, c->datt, mpad, kv_nt);
                 else
                     wh_launch_dec_cross_attn(s, prec, c->dq, (char*)c->cross_kv + (2 * l) * kv_stride * esz,
                                              (char*)c->cross_kv + (2 * l + 1) * kv_stride * esz, c->cpart, c->cml,
-                                             (int)S, (int)d, D.n_heads, c->cross_splits, nb, c->datt, mpad);
+                                             (int)S, (int)d, D.n_heads, c->cross_splits, nb, c->datt, mpad, kv_nt);
             }
             {   // merge of the key ranges ∘ cross-attention out-proj + residual → x, raw slab, LN3 partials
                 Prof pr(c, WH_KG_DEC_GEMM);

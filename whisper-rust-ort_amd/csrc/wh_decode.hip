@@ -743,7 +743,7 @@ __global__ __launch_bounds__(64) void k_dec_self_attn(const T* __restrict__ qkv,
 // acquire around an arrival ticket) and writes the attention output.
 //   ck/cv: [B][S][d]  (head h at columns h*64..h*64+63),   q: [B][d] pre-scaled
 //   part : [B][splits][d] unnormalised partial outputs, ml: [B][splits][H][2] (max, sum)
-template <typename T, int NCH, int UNROLL>  // NCH = ceil(d*sizeof(T)/16 / 64): 16-B chunks per lane per row
+template <typename T, int NCH, int UNROLL, bool NT>  // NCH = ceil(d*sizeof(T)/16 / 64): 16-B chunks per lane per row; NT: non-temporal K/V loads
 __global__ __launch_bounds__(256) void k_dec_cross_attn(const T* __restrict__ q, const T* __restrict__ ck,
                                                         const T* __restrict__ cv, float* __restrict__ part,
                                                         float* __restrict__ ml, int S, int d, int n_heads,
@@ -790,8 +790,16 @@ __global__ __launch_bounds__(256) void k_dec_cross_attn(const T* __restrict__ q,
             for (int c = 0; c < NCH; c++) {
                 const int ch = lane + 64 * c;
                 if (ch < chunks) {
-                    kk[u][c] = *reinterpret_cast<const vec_t*>(kb + (long)jj * d + ch * EPC);
-                    vv[u][c] = *reinterpret_cast<const vec_t*>(vb + (long)jj * d + ch * EPC);
+                    // read-once stream: non-temporal, so that the K/V bytes of a launch (hundreds of MB) do not evict the
+                    // decode weights and activations from L2 / the Infinity Cache between the surrounding small GEMMs
+                    // (only when the whole cross K/V set is larger than the Infinity Cache: a small batch re-reads it from there)
+                    if constexpr (NT) {
+                        kk[u][c] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(kb + (long)jj * d + ch * EPC));
+                        vv[u][c] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(vb + (long)jj * d + ch * EPC));
+                    } else {
+                        kk[u][c] = *reinterpret_cast<const vec_t*>(kb + (long)jj * d + ch * EPC);
+                        vv[u][c] = *reinterpret_cast<const vec_t*>(vb + (long)jj * d + ch * EPC);
+                    }
                 }
             }
         }
@@ -1043,11 +1051,12 @@ void wh_launch_dec_self_attn(hipStream_t s, int prec, const void* qkv, void* kc,
 }
 
 void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void* ck, const void* cv, float* part,
-                              float* ml, int S, int d, int n_heads, int splits, int B, void* out, int mpad) {
+                              float* ml, int S, int d, int n_heads, int splits, int B, void* out, int mpad, bool stream_nt) {
     dim3 grid(splits, B);
     const size_t sm = sizeof(float) * ((size_t)8 * n_heads + 4 * (size_t)d);
-#define WH_CA(T_, N_, U_) hipLaunchKernelGGL((k_dec_cross_attn<T_, N_, U_>), grid, dim3(256), sm, s, (const T_*)q, (const T_*)ck, \
+#define WH_CA1(T_, N_, U_, NT_) hipLaunchKernelGGL((k_dec_cross_attn<T_, N_, U_, NT_>), grid, dim3(256), sm, s, (const T_*)q, (const T_*)ck, \
                                              (const T_*)cv, part, ml, S, d, n_heads, splits, (T_*)(splits == 1 ? out : nullptr), mpad)
+#define WH_CA(T_, N_, U_) do { if (stream_nt) WH_CA1(T_, N_, U_, true); else WH_CA1(T_, N_, U_, false); } while (0)
     if (prec == WH_PREC_F32) {
         const int nch = (d / 4 + 63) / 64;  // f32: 4 elements per chunk
         if (nch == 1) WH_CA(float, 1, 4);
@@ -1059,4 +1068,5 @@ void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void
         else WH_CA(bf16, 3, 2);
     }
 #undef WH_CA
+#undef WH_CA1
 }

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_kv_quant(const bf16* __restrict__ kv, c
 // else 1 with NCH chunks per lane).  Online softmax per (lane group, key slot); the KPI slots and the 4 waves are
 // merged through LDS, the key ranges of a clip by the consumer GEMM (frag merge in k_dec_gemm).
 //   ck/cv: [B][S][d] e4m3 codes,  q: [B][d] bf16 pre-scaled by head_dim^-0.5,  amax_k/amax_v: [B][H]
-template <int KPI, int NCH, int UNROLL>
+template <int KPI, int NCH, int UNROLL, bool NT>
 __global__ __launch_bounds__(256) void k_dec_cross_attn8(const bf16* __restrict__ q, const unsigned char* __restrict__ ck,
                                                          const unsigned char* __restrict__ cv,
                                                          const float* __restrict__ amax_k, const float* __restrict__ amax_v,
@@ -125,8 +125,14 @@ __global__ __launch_bounds__(256) void k_dec_cross_attn8(const bf16* __restrict_
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
                 const int ch = live[c] ? lch + 64 * c : 0;
-                kk[u][c] = *reinterpret_cast<const wh_u32x4*>(kb + (long)jj * d + ch * 16);
-                vv[u][c] = *reinterpret_cast<const wh_u32x4*>(vb + (long)jj * d + ch * 16);
+                // read-once stream: non-temporal (keeps the decode weights resident in L2 / the Infinity Cache)
+                if constexpr (NT) {
+                    kk[u][c] = __builtin_nontemporal_load(reinterpret_cast<const wh_u32x4*>(kb + (long)jj * d + ch * 16));
+                    vv[u][c] = __builtin_nontemporal_load(reinterpret_cast<const wh_u32x4*>(vb + (long)jj * d + ch * 16));
+                } else {
+                    kk[u][c] = *reinterpret_cast<const wh_u32x4*>(kb + (long)jj * d + ch * 16);
+                    vv[u][c] = *reinterpret_cast<const wh_u32x4*>(vb + (long)jj * d + ch * 16);
+                }
             }
         }
     };
@@ -236,11 +242,16 @@ __global__ __launch_bounds__(256) void k_dec_cross_attn8(const bf16* __restrict_
 
 template <int KPI, int NCH, int UNROLL>
 void launch_ca8(hipStream_t s, const void* q, const void* ck, const void* cv, const float* amax_k, const float* amax_v, float* part,
-                float* ml, int S, int d, int n_heads, int splits, int B, void* out, int mpad) {
+                float* ml, int S, int d, int n_heads, int splits, int B, void* out, int mpad, bool stream_nt) {
     const size_t sm = sizeof(float) * ((size_t)2 * 4 * KPI * n_heads + (size_t)4 * KPI * d);
-    hipLaunchKernelGGL((k_dec_cross_attn8<KPI, NCH, UNROLL>), dim3(splits, B), dim3(256), sm, s, (const bf16*)q,
-                       (const unsigned char*)ck, (const unsigned char*)cv, amax_k, amax_v, part, ml, S, d, n_heads, splits,
-                       (bf16*)(splits == 1 ? out : nullptr), mpad);
+    if (stream_nt)
+        hipLaunchKernelGGL((k_dec_cross_attn8<KPI, NCH, UNROLL, true>), dim3(splits, B), dim3(256), sm, s, (const bf16*)q,
+                           (const unsigned char*)ck, (const unsigned char*)cv, amax_k, amax_v, part, ml, S, d, n_heads, splits,
+                           (bf16*)(splits == 1 ? out : nullptr), mpad);
+    else
+        hipLaunchKernelGGL((k_dec_cross_attn8<KPI, NCH, UNROLL, false>), dim3(splits, B), dim3(256), sm, s, (const bf16*)q,
+                           (const unsigned char*)ck, (const unsigned char*)cv, amax_k, amax_v, part, ml, S, d, n_heads, splits,
+                           (bf16*)(splits == 1 ? out : nullptr), mpad);
 }
 
 }  // namespace
@@ -257,11 +268,11 @@ void wh_launch_kv_quant(hipStream_t s, const void* kv_bf16, unsigned* amax, void
 
 void wh_launch_dec_cross_attn8(hipStream_t s, const void* q, const void* ck, const void* cv, const float* amax_k,
                                const float* amax_v, float* part, float* ml, int S, int d, int n_heads, int splits, int B, void* out,
-                               int mpad) {
+                               int mpad, bool stream_nt) {
     const int chunks = d / 16;
-    if (chunks == 32) launch_ca8<2, 1, 4>(s, q, ck, cv, amax_k, amax_v, part, ml, S, d, n_heads, splits, B, out, mpad);       // d = 512
-    else if (chunks == 16) launch_ca8<4, 1, 2>(s, q, ck, cv, amax_k, amax_v, part, ml, S, d, n_heads, splits, B, out, mpad);  // d = 256
-    else if (chunks == 8) launch_ca8<8, 1, 1>(s, q, ck, cv, amax_k, amax_v, part, ml, S, d, n_heads, splits, B, out, mpad);   // d = 128
-    else if (chunks <= 64) launch_ca8<1, 1, 4>(s, q, ck, cv, amax_k, amax_v, part, ml, S, d, n_heads, splits, B, out, mpad);  // d <= 1024
-    else launch_ca8<1, 2, 2>(s, q, ck, cv, amax_k, amax_v, part, ml, S, d, n_heads, splits, B, out, mpad);                    // d = 1280
+    if (chunks == 32) launch_ca8<2, 1, 4>(s, q, ck, cv, amax_k, amax_v, part, ml, S, d, n_heads, splits, B, out, mpad, stream_nt);       // d = 512
+    else if (chunks == 16) launch_ca8<4, 1, 2>(s, q, ck, cv, amax_k, amax_v, part, ml, S, d, n_heads, splits, B, out, mpad, stream_nt);  // d = 256
+    else if (chunks == 8) launch_ca8<8, 1, 1>(s, q, ck, cv, amax_k, amax_v, part, ml, S, d, n_heads, splits, B, out, mpad, stream_nt);   // d = 128
+    else if (chunks <= 64) launch_ca8<1, 1, 4>(s, q, ck, cv, amax_k, amax_v, part, ml, S, d, n_heads, splits, B, out, mpad, stream_nt);  // d <= 1024
+    else launch_ca8<1, 2, 2>(s, q, ck, cv, amax_k, amax_v, part, ml, S, d, n_heads, splits, B, out, mpad, stream_nt);                    // d = 1280
 }

@@ -117,16 +117,17 @@ void wh_launch_argmax_finish(hipStream_t s, int prec, const float* part_val, con
                              int* ticket, const DecodeState& st, int B, const NextEmbed& ne);
 void wh_launch_dec_self_attn(hipStream_t s, int prec, const void* qkv, void* kc, void* vc, void* out, const int* pos_p,
                              int d, int n_heads, int tc, int B, int mpad);
+// stream_nt: non-temporal K/V loads (set when the cross K/V of all layers exceed what the Infinity Cache can keep)
 // splits == 1: the normalised output goes straight to `out` (slab layout, row pitch mpad); else partials for the consumer's merge
 void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void* ck, const void* cv, float* part,
-                              float* ml, int S, int d, int n_heads, int splits, int B, void* out, int mpad);
+                              float* ml, int S, int d, int n_heads, int splits, int B, void* out, int mpad, bool stream_nt);
 
 // WH_PREC_FP8 (wh_fp8.hip)
 void wh_launch_kv_quant(hipStream_t s, const void* kv_bf16, unsigned* amax, void* kv8, long planes_x_clips, int S, int d,
                         int n_heads);
 void wh_launch_dec_cross_attn8(hipStream_t s, const void* q, const void* ck, const void* cv, const float* amax_k,
                                const float* amax_v, float* part, float* ml, int S, int d, int n_heads, int splits, int B, void* out,
-                               int mpad);
+                               int mpad, bool stream_nt);
 
 extern int wh_dbg_cross_unroll;
 extern int wh_dbg_lm_blocks_per_cu;
