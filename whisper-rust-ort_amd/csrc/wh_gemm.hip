@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         const long mb = m / g.m_per, mi = m % g.m_per;
         f32x4 v = *reinterpret_cast<const f32x4*>(&Ts[lr * LDT + c4]);
         if (R) {
-            const f32x4 r = *reinterpret_cast<const f32x4*>(R + mb * g.r_bs + mi * g.ldr + n);
+            const f32x4 r = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(R + mb * g.r_bs + mi * g.ldr + n));  // read once
             v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
         }
         store4(C + mb * g.c_bs + mi * g.ldc + nc0 + c4, v[0], v[1], v[2], v[3]);
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
 #pragma unroll
     for (int i = 0; i < MAXV; i++) {
         if (i < nv) {
-            v[i] = *reinterpret_cast<const f32x4*>(xr + (i * 64 + lane) * 4);
+            v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + (i * 64 + lane) * 4));  // read once
             s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
         }
     }
