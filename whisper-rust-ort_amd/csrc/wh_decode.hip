@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void k_dec_embed(const T* __restrict__ tok_emb
         s1 += (v[0] + v[1]) + (v[2] + v[3]);
         s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
+    s1 = dpp_wave_sum(s1);
+    s2 = dpp_wave_sum(s2);
     if (lane == 0) { stats[2 * row] = s1; stats[2 * row + 1] = s2; }
 }
 
@@ -617,8 +617,8 @@ __global__ __launch_bounds__(256) void k_argmax_finish(const float* __restrict__
             s1 += (v[0] + v[1]) + (v[2] + v[3]);
             s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
         }
-        s1 = wave_sum(s1);
-        s2 = wave_sum(s2);
+        s1 = dpp_wave_sum(s1);
+        s2 = dpp_wave_sum(s2);
         if ((tid & 63) == 0) { sv[tid >> 6] = s1; sv[4 + (tid >> 6)] = s2; }
         __syncthreads();
         if (tid == 0) {

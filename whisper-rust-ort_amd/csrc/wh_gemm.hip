@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
         tv = *reinterpret_cast<const f32x4*>(xr + nv * 256 + lane * 4);
         s += tv[0] + tv[1] + tv[2] + tv[3];
     }
-    const float mean = wave_sum(s) / (float)d;
+    const float mean = dpp_wave_sum(s) / (float)d;
     float q = 0.0f;
 #pragma unroll
     for (int i = 0; i < MAXV; i++) {
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
 #pragma unroll
         for (int e = 0; e < 4; e++) { float t = tv[e] - mean; q += t * t; }
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+    const float rstd = rsqrtf(dpp_wave_sum(q) / (float)d + 1e-5f);
     TO* yr = y + row * d;
 #pragma unroll
     for (int i = 0; i < MAXV; i++) {

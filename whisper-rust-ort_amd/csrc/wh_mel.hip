@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_mel_stft(const float* __restrict__ pcm,
                 if (f0 + 4 * g + r < n_frames) out[r] = v[r];
         }
     }
-    lmax = wave_max(lmax);
+    lmax = dpp_wave_max(lmax);
     if (lane == 0 && lmax > -INFINITY) atomicMax(gmax + clip, f2ord(lmax));
 }
 
