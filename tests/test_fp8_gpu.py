@@ -108,3 +108,23 @@ def test_prequantised_checkpoint_equals_load_time_quantisation(gpu, tmp_path):
     assert t_dst.tolist() == t_ref.tolist() and np.array_equal(l_dst, l_ref)
     t_bf, _ = run(str(dst), wb.WH_PREC_BF16)
     assert len(t_bf) == len(t_ref) and all(0 <= t < dims.vocab for t in t_bf.tolist())
+
+
+def test_fp8_base_256_clip_batch_matches_64_clip_batches(gpu):
+    """fp8 twin of test_base_bf16_256_clip_batch_matches_64_clip_batches: one key range per clip with the attention
+    kernel writing its output directly and the K/V stream loaded non-temporally (256 clips) against four key ranges
+    merged in the out-projection GEMM (32 clips on a 64-clip context); per-clip K/V scales make clips independent."""
+    dims = ms.PRESETS["base"]
+    model = wb.Model("synthetic:base:1234", 0, wb.WH_PREC_FP8)
+    prompt, eot = small_prompt(dims)
+    distinct = [ms.synth_clip(300 + i) for i in range(32)]
+    params = wb.DecodeParams(prompt, 40, eot, [eot])
+    ctx64 = wb.Context(model, 64)
+    ref = [t.tolist() for t in ctx64.transcribe_batch(distinct, params)]
+    ctx64.close()
+    ctx256 = wb.Context(model, 256)
+    full = [t.tolist() for t in ctx256.transcribe_batch([distinct[i % 32] for i in range(256)], params)]
+    assert all(len(t) == len(prompt) + 40 for t in full)
+    for i in range(32, 256):
+        assert full[i] == full[i % 32]
+    assert full[:32] == ref
