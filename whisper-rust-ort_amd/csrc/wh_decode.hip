@@ -964,12 +964,20 @@ void launch_dec_gemm_mt(hipStream_t s, const SkinnyArgs& a) {
     }
 }
 
+// K split over the waves of a workgroup: 8 ways when K is deep, when X is merged from attention partials, or when the
+// launch would otherwise put fewer than ~128 workgroups on the chip (small batch x narrow N: more waves per
+// workgroup keep more weight bytes in flight per CU); else 4.  Needs K % 256 == 0.
+static inline bool dec_gemm_8way(const SkinnyArgs& a) {
+    const long wgs = (long)((a.N + 15) / 16) * ((a.M + 15) / 16);
+    return (a.K >= 2048 || a.xpart || (wgs < 128 && a.K >= 1024)) && a.K % 256 == 0;
+}
+
 template <typename T, typename TO, typename TW>
 void launch_dec_gemm_split(hipStream_t s, const SkinnyArgs& a) {
     // K is split over the waves of a workgroup: 8 ways when it is deep, else 4 (K % 128 == 0 always
     // holds: d_model and ffn are multiples of 128, checked at model load)
     // (X from attention partials: 8 ways too — fewer fragments to merge per lane)
-    if ((a.K >= 2048 || a.xpart) && a.K % 256 == 0) launch_dec_gemm_mt<T, TO, 8, TW>(s, a);
+    if (dec_gemm_8way(a)) launch_dec_gemm_mt<T, TO, 8, TW>(s, a);
     else launch_dec_gemm_mt<T, TO, 4, TW>(s, a);
 }
 
@@ -979,7 +987,7 @@ void wh_launch_dec_gemm(hipStream_t s, int prec, bool out_f32, const SkinnyArgs&
     if (prec == WH_PREC_F32) launch_dec_gemm_split<float, float, float>(s, a);
     else if (prec == WH_PREC_FP8 && a.wscale) {  // e4m3 weight codes, bf16 activations
         // 16 codes per lane per load when every wave's K share is a multiple of 64, else 8
-        const int nw = ((a.K >= 2048 || a.xpart) && a.K % 256 == 0) ? 8 : 4;
+        const int nw = dec_gemm_8way(a) ? 8 : 4;
         const bool wide = (a.K / nw) % 64 == 0;
         if (wide) { if (out_f32) launch_dec_gemm_split<bf16, float, fp8x16_t>(s, a); else launch_dec_gemm_split<bf16, bf16, fp8x16_t>(s, a); }
         else { if (out_f32) launch_dec_gemm_split<bf16, float, fp8x8_t>(s, a); else launch_dec_gemm_split<bf16, bf16, fp8x8_t>(s, a); }
