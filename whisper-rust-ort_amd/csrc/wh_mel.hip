@@ -72,7 +72,15 @@ __global__ __launch_bounds__(256) void k_mel_stft(const float* __restrict__ pcm,
         tw[i] = tw_g[i];
         win[i] = win_g[i];
     }
-    for (int i = tid; i < SPAN; i += 256) smp[i] = padded_sample(cp, n, f0 * HOP + i);
+    {   // all of a thread's samples in flight before the LDS stores (SPAN / 256 = 11 loads)
+        constexpr int NS = (SPAN + 255) / 256;
+        float sv[NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++) sv[i] = padded_sample(cp, n, f0 * HOP + min(tid + i * 256, SPAN - 1));
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+            if (tid + i * 256 < SPAN) smp[tid + i * 256] = sv[i];
+    }
     __syncthreads();
 
     // ---- DFT on the f64 matrix cores -----------------------------------------------------------
@@ -140,6 +148,7 @@ __global__ __launch_bounds__(256) void k_mel_stft(const float* __restrict__ pcm,
     for (int mt = wave; mt < n_mt; mt += 4) {
         f32x4 acc = {0, 0, 0, 0};
         const int mel = 16 * mt + fl;
+#pragma unroll 13
         for (int step = 0; step < NBIN_PAD / 4; step++) {
             const int k = 4 * step + g;
             float a = pw[fl][k];
