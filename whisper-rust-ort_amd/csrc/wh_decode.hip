@@ -657,12 +657,16 @@ __global__ __launch_bounds__(64) void k_dec_self_attn(const T* __restrict__ qkv,
             for (int e = 0; e < HD / 8; e++) kr[i][e] = load_frag<T>(kcb + (long)j * HD + e * 8);
         }
     }
-    // ... and so do the first VPRE cached V rows (lane e reads column e): P·V then starts without a memory round
-    // trip, and what is left is fetched VPRE rows at a time (the loop used to pay one round trip per 8 rows)
-    constexpr int VPRE = 32;
-    T vpre[VPRE];
+    // ... and so do the first NPRE * RPI cached V rows, 16 bytes per lane: lane = (row slot, 16-byte chunk of the row), one
+    // wave instruction covers RPI whole rows (8 for bf16, 4 for f32) instead of one row as 64 two-byte loads
+    constexpr int EPC = 16 / (int)sizeof(T), CPR = HD / EPC, RPI = 64 / CPR, NPRE = 8;
+    typedef __attribute__((ext_vector_type(EPC))) T vrow_t;
+    const int rslot = lane / CPR, chunk = lane % CPR;
+    vrow_t vpre[NPRE];
 #pragma unroll
-    for (int u = 0; u < VPRE; u++) vpre[u] = vcb[(long)min(u, tc - 1) * HD + lane];  // unconditional: rows >= pos are masked below
+    for (int u = 0; u < NPRE; u++)  // unconditional: rows >= pos are masked below
+        vpre[u] = *reinterpret_cast<const vrow_t*>(vcb + (long)min(u * RPI + rslot, tc - 1) * HD + chunk * EPC);
+    const vrow_t vcur_v = *reinterpret_cast<const vrow_t*>(row + 2 * d + h * HD + chunk * EPC);
     const T kcur = row[d + h * HD + lane], vcur = row[2 * d + h * HD + lane];
     qs[lane] = cvt_in<T>(row[h * HD + lane]);
     kcb[(long)pos * HD + lane] = kcur;
@@ -705,32 +709,45 @@ __global__ __launch_bounds__(64) void k_dec_self_attn(const T* __restrict__ qkv,
     const float pcur = __expf(scur - mx);
     sum = dpp_wave_sum(sum) + pcur;
     __syncthreads();
-    // 3. P·V: eight cached rows in flight at a time; probabilities are LDS broadcasts
-    float o = pcur * cvt_in<T>(vcur);
+    // 3. P·V: lane accumulates its chunk's EPC columns over the rows of its slot; the RPI slots are summed at the end
+    float o[EPC];
 #pragma unroll
-    for (int u = 0; u < VPRE; u++) {
-        const float t = sc[u] * cvt_in<T>(vpre[u]);
-        o += (u < pos) ? t : 0.0f;  // select, not a branch (and never garbage * 0)
+    for (int e = 0; e < EPC; e++) o[e] = (rslot == 0) ? pcur * cvt_in<T>(vcur_v[e]) : 0.0f;
+#pragma unroll
+    for (int u = 0; u < NPRE; u++) {
+        const int r = u * RPI + rslot;
+        const float pr = (r < pos) ? sc[min(r, 511)] : 0.0f;  // select: a row beyond pos contributes exactly 0
+#pragma unroll
+        for (int e = 0; e < EPC; e++) o[e] += (r < pos) ? pr * cvt_in<T>(vpre[u][e]) : 0.0f;
     }
-    int j = VPRE;
-    for (; j + VPRE <= pos; j += VPRE) {
-        T v[VPRE];
+    for (int j = NPRE * RPI; j < pos; j += NPRE * RPI) {  // later rows: NPRE wide loads in flight, clamped and masked
+        vrow_t v[NPRE];
 #pragma unroll
-        for (int u = 0; u < VPRE; u++) v[u] = vcb[(long)(j + u) * HD + lane];
+        for (int u = 0; u < NPRE; u++)
+            v[u] = *reinterpret_cast<const vrow_t*>(vcb + (long)min(j + u * RPI + rslot, tc - 1) * HD + chunk * EPC);
 #pragma unroll
-        for (int u = 0; u < VPRE; u++) o += sc[j + u] * cvt_in<T>(v[u]);
-    }
-    for (; j < pos; j += 8) {  // tail groups: clamped rows, masked products — never a one-row-per-round-trip loop
-        T v[8];
+        for (int u = 0; u < NPRE; u++) {
+            const int r = j + u * RPI + rslot;
+            const float pr = (r < pos) ? sc[min(r, 511)] : 0.0f;
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = vcb[(long)min(j + u, tc - 1) * HD + lane];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const float t = sc[min(j + u, 511)] * cvt_in<T>(v[u]);
-            o += (j + u < pos) ? t : 0.0f;
+            for (int e = 0; e < EPC; e++) o[e] += (r < pos) ? pr * cvt_in<T>(v[u][e]) : 0.0f;
         }
     }
-    out[slab_idx(b, h * HD + lane, mpad)] = cvt_out<T>(o / sum);
+    // sum over the row slots (lanes with equal chunk): lane ^ 8 inside a 16-lane row by DPP (bf16 only: 8 chunks per
+    // row), then across the four rows of the wave
+#pragma unroll
+    for (int e = 0; e < EPC; e++) {
+        float t = o[e];
+        if (CPR == 8) t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x128, 0xF, 0xF, true));  // row_ror:8
+        o[e] = xrow_sum(t);
+    }
+    if (rslot == 0) {
+        const float inv = 1.0f / sum;
+        vrow_t ov;
+#pragma unroll
+        for (int e = 0; e < EPC; e++) ov[e] = cvt_out<T>(o[e] * inv);
+        *reinterpret_cast<vrow_t*>(out + slab_idx(b, h * HD + chunk * EPC, mpad)) = ov;
+    }
 }
 
 // ---- decoder cross-attention, one position ([3P] :433-440, 478-491) -----------------------------
