@@ -104,6 +104,50 @@ def cpu_baseline(dims, seed: int, prompt, eot, max_new: int) -> dict:
             "seconds": t3 - t0, "tokens": [int(t) for t in toks[:8]]}
 
 
+def self_launch(n: int) -> int:
+    """One process per GPU: start n copies of this script as children with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set, relay rank 0's stdout (the JSON line), return non-zero if any rank fails.
+    Children are separate processes (subprocess, never exec) and are ended by their exact PIDs on failure."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    out0 = b""
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                try:
+                    if r == 0:
+                        o, _ = procs[0].communicate(timeout=0.5)
+                        out0 += o or b""
+                    else:
+                        procs[r].wait(timeout=0.5)
+                except subprocess.TimeoutExpired:
+                    continue
+                pending.discard(r)
+                if procs[r].returncode != 0:
+                    rc = rc or procs[r].returncode or 1
+                    print(f"[bench] rank {r} exited with {procs[r].returncode}", file=sys.stderr)
+                    for q in pending:      # a dead rank would leave the others waiting in a barrier
+                        procs[q].terminate()
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,14 +168,38 @@ def main() -> None:
     ap.add_argument("--graph-timed", action="store_true",
                     help="experiment: no HIP events in the timed region (decode replays its hipGraph); roofline then comes from the profiled pass")
     ap.add_argument("--profile-all", action="store_true", help="event-time every kernel group in the timed region")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="no GPU work: every rank joins a gloo group, gathers one dummy record and rank 0 prints what it saw "
+                         "(CPU test of the launcher and the rendezvous)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  It has not touched HIP (the
+        # binding loads libwhisper_hip.so lazily) and never will: it starts one child per GPU and relays rank 0.
+        raise SystemExit(self_launch(a.gpus))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {a.gpus}: launch one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself)")
+    if a.launch_check:
+        import torch.distributed as dist
+        from whisper_rust_ort_amd import sharding
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ids = sharding.shard_clip_ids(rank, world, 2)
+        rec = sharding.gather_records(dist, sharding.pack_records(ids, [np.array([rank, local_rank])] * 2, 4))
+        tmax = sharding.max_over_ranks(dist, float(rank))
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "world": world, "max_rank": tmax,
+                              "records": [[c, t.tolist()] for c, t in sharding.unpack_records(rec)]}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     dist = None
     backend = "none"
     if world > 1 or a.force_dist:

@@ -80,3 +80,22 @@ def test_record_packing_roundtrip_and_bounds():
     with pytest.raises(ValueError):
         sharding.pack_records([0], [np.arange(11)], 10)
     assert sharding.shard_clip_ids(3, 8, 64) == list(range(192, 256))
+
+
+def test_bench_self_launches_one_rank_per_gpu():
+    """`python bench.py --gpus N` (the driver's plain command) must start the N ranks itself: the parent never
+    touches HIP, the children get RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, rank 0's line is relayed."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["launch_check"] and line["world"] == 2 and line["max_rank"] == 1.0
+    assert [c for c, _ in line["records"]] == [0, 1, 2, 3]
+    assert [t for _, t in line["records"]] == [[0, 0], [0, 0], [1, 1], [1, 1]]     # [rank, local_rank] per clip
+    # a launch whose world size disagrees with --gpus is refused
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--launch-check"],
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "does not match --gpus" in bad.stderr
