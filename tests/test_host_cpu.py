@@ -215,3 +215,39 @@ def test_cli_flag_surface_and_loud_failure_without_gpu():
         assert flag in h, flag                                                          # src/main.rs:23-86
     r = subprocess.run([cli, "--bogus", "1"], capture_output=True, text=True)
     assert r.returncode == 2 and "unexpected argument" in r.stderr
+
+
+def test_results_table_from_summaries(tmp_path):
+    """summary JSONs (reference schema, src/main.rs:1235-1257, and ours with the additive gpu{} key) →
+    the md/csv table of compare_container_benchmarks.py:118-226 (same columns, same csv fields, same fallbacks)."""
+    import csv
+    import json
+    from whisper_rust_ort_amd import results_table as rt
+    ref = {"config_used": {"intra_op": 1}, "n_files": 1,
+           "latency_end_to_end_s": {"min": 14.884, "median": 14.884, "p90": 14.884, "p95": 14.884, "max": 14.884, "mean": 14.884},
+           "rtf_end_to_end": {"p95": 0.04936, "median": 0.04936}, "model_id": "openai/whisper-base"}
+    ours = {"config_used": {}, "n_files": 512, "latency_end_to_end_s": {"p95": None, "median": 0.0704, "mean": 0.07},
+            "rtfx_end_to_end": {"p95": 27000.0}, "gpu": {"backend": "libwhisper_hip (gfx950)", "precision": "bf16", "device": 0}}
+    int8 = {"config_used": {"compute_type": "QInt8", "beam_size": "5"}, "latency_end_to_end_s": {}}
+    for name, s in (("without_hf_pipeline_rust", ref), ("mi355x_bf16", ours), ("faster_whisper_int8", int8)):
+        (tmp_path / name).mkdir()
+        (tmp_path / name / "inference_summary.json").write_text(json.dumps(s))
+    logs = tmp_path / "logs"
+    logs.mkdir()
+    (logs / "faster_whisper_int8.time.txt").write_text(
+        "\tElapsed (wall clock) time (h:mm:ss or m:ss): 1:02:03\n\tMaximum resident set size (kbytes): 2177024\n")
+    md, cs = tmp_path / "t.md", tmp_path / "t.csv"
+    assert rt.main(["--results-dir", str(tmp_path), "--log-dir", str(logs), "--out-md", str(md), "--out-csv", str(cs)]) == 0
+    lines = md.read_text().splitlines()
+    assert lines[0] == "| Implementation | Precision | Beam size | Time | RAM Usage |" and lines[1] == "| --- | --- | --- | --- | --- |"
+    assert "| faster_whisper_int8 | int8 | 5 | 1h02m03s | 2126MB |" in lines          # time and RAM from the /usr/bin/time log
+    assert "| libwhisper_hip (gfx950) [mi355x_bf16] | bf16 | 1 | 0s | n/a |" in lines   # p95 null → median (fallback order)
+    assert "| without_hf_pipeline_rust | fp32 | 1 | 15s | n/a |" in lines
+    rows = list(csv.DictReader(cs.open()))
+    assert list(rows[0].keys()) == ["implementation", "precision", "beam_size", "time_s", "ram_mb"]
+    by = {r["implementation"]: r for r in rows}
+    assert by["without_hf_pipeline_rust"]["time_s"] == "14.884" and by["faster_whisper_int8"]["time_s"] == "3723.0"
+    assert rt.human_time(75) == "1m15s" and rt.human_time(None) == "n/a"
+    rt.main(["--summary", f"GPU run={tmp_path / 'mi355x_bf16' / 'inference_summary.json'}", "--out-md", str(md), "--out-csv", str(cs),
+             "--extra-columns"])
+    assert "| GPU run | bf16 | 1 | 0s | n/a | 512 | 27000.0 |" in md.read_text()
