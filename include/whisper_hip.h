@@ -139,6 +139,15 @@ int wh_encode(wh_ctx* c, const float* mel, float* enc_out);
 int wh_decode_greedy(wh_ctx* c, const wh_decode_params* p, int64_t* tokens_out, size_t cap_tokens,
                      size_t* n_tokens_out, float* logits_out, size_t cap_logits_rows);
 
+/* Parity harness (no reference counterpart: the reference decodes one window per call): the same greedy decode over
+ * ALL clips whose encoder states are resident in the ctx — the n clips of the last wh_transcribe_batch* /
+ * wh_transcribe_longform batch, or the one clip of wh_encode — run as ONE batch, i.e. through the batched kernel
+ * variants the throughput path uses, with the logits read back.  tokens_out: [n][cap_tokens]; n_tokens_out: [n];
+ * logits_out (optional): [n][cap_logits_rows][vocab] f32, row i of clip b = logits that chose its generated token i.
+ * `forced` in the params applies the same token history to every clip.  *n_clips_out = n. */
+int wh_decode_greedy_batch(wh_ctx* c, const wh_decode_params* p, int64_t* tokens_out, size_t cap_tokens, size_t* n_tokens_out,
+                           size_t cap_clips, size_t* n_clips_out, float* logits_out, size_t cap_logits_rows);
+
 /* ---- fused batch call: the body of transcribe_longform_chunked for ≤ max_batch single-window
  * clips (src/main.rs:870-915 / 946-967) run as one batch on the ctx stream -------------------- */
 typedef struct {

@@ -118,7 +118,9 @@ def make(preset: str, seed: int, clip: int, max_new: int, out_dir: str) -> str:
         enc = model.model.encoder(torch.from_numpy(mel)[None]).last_hidden_state
     enc_np = enc[0].numpy().astype(np.float32)
 
-    if dims.vocab > 50400:
+    if dims.vocab == 51866:
+        prompt, eot = [50258, 50259, 50360, 50364], 50257  # large-v3 ids of the same four specials (one more language token)
+    elif dims.vocab > 50400:
         prompt, eot = [50258, 50259, 50359, 50363], 50257  # reference src/main.rs:549-566
     else:
         prompt, eot = [3, 5, 7, 9], 2
@@ -177,7 +179,7 @@ def main() -> None:
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     jobs = [("nano", 7, 0, 24), ("nano", 7, 1, 24), ("micro", 11, 2, 32), ("base", 1234, 0, 128),
-            ("base", 1234, 3, 128)]
+            ("base", 1234, 3, 128), ("large-v3", 5, 7, 12)]
     for preset, seed, clip, max_new in jobs:
         if a.only and a.only != preset:
             continue

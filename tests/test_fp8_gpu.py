@@ -110,28 +110,12 @@ def test_prequantised_checkpoint_equals_load_time_quantisation(gpu, tmp_path):
     assert len(t_bf) == len(t_ref) and all(0 <= t < dims.vocab for t in t_bf.tolist())
 
 
-def test_fp8_base_256_clip_batch_matches_64_clip_batches(gpu):
-    """fp8 twin of test_base_bf16_256_clip_batch_matches_64_clip_batches: one key range per clip with the attention
-    kernel writing its output directly and the K/V stream loaded non-temporally (256 clips) against four key ranges
-    merged in the out-projection GEMM (32 clips on a 64-clip context); per-clip K/V scales make clips independent."""
-    dims = ms.PRESETS["base"]
-    model = wb.Model("synthetic:base:1234", 0, wb.WH_PREC_FP8)
-    prompt, eot = small_prompt(dims)
-    distinct = [ms.synth_clip(300 + i) for i in range(32)]
-    params = wb.DecodeParams(prompt, 40, eot, [eot])
-    ctx64 = wb.Context(model, 64)
-    ref = [t.tolist() for t in ctx64.transcribe_batch(distinct, params)]
-    ctx64.close()
-    ctx256 = wb.Context(model, 256)
-    full = [t.tolist() for t in ctx256.transcribe_batch([distinct[i % 32] for i in range(256)], params)]
-    assert all(len(t) == len(prompt) + 40 for t in full)
-    for i in range(32, 256):
-        assert full[i] == full[i % 32]
-    # The two contexts split a clip's keys differently (one range vs four merged ranges): the same arithmetic in a different
-    # summation order, so a near-tie of the flat synthetic logits may flip one token and the clip then decodes on from there.
-    # Everything that shares a context configuration is exact (duplicates above, test_base_bf16_full_batch_properties).
-    diverged = [i for i in range(32) if full[i] != ref[i]]
-    assert len(diverged) <= 4, diverged
-    for i in diverged:
-        first = next(k for k in range(len(ref[i])) if full[i][k] != ref[i][k])
-        assert first > len(prompt), (i, first)   # never at the first generated token: that one has no accumulated history
+def test_fp8_base_256_vs_64_clip_context_logit_bound(gpu, golden_dir):
+    """fp8 twin of test_base_bf16_256_vs_64_clip_context_logit_bound: one key range per clip with the attention kernel
+    writing its output directly and the K/V stream loaded non-temporally (256 clips) against four key ranges merged in the
+    out-projection GEMM (64-clip context); per-clip K/V scales keep clips independent.  Teacher-forced, per-row bound."""
+    from test_hip_parity import _ctx_logit_compare
+    d_ctx, e256, e64, e3 = _ctx_logit_compare(wb.WH_PREC_FP8, golden_dir, "fp8")
+    assert d_ctx.max() < 0.15
+    # e4m3 weights + e4m3 cross K/V against the f32 golden vectors: reported (profiles/*fp8_accuracy*), loosely bounded here
+    assert max(e256, e64, e3) < 1.5

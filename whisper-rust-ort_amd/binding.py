@@ -31,7 +31,7 @@ STATUS = {0: "WH_OK", 1: "WH_ERR_EMPTY_AUDIO", 2: "WH_ERR_BAD_SHAPE", 3: "WH_ERR
 # every symbol include/whisper_hip.h declares
 EXPORTS = ("wh_model_load", "wh_model_create", "wh_model_free", "wh_model_get_dims", "wh_model_precision",
            "wh_model_export_tensor", "wh_ctx_create", "wh_ctx_free", "wh_last_error", "wh_get_timings",
-           "wh_mel_frames", "wh_log_mel", "wh_encode", "wh_decode_greedy", "wh_transcribe_batch",
+           "wh_mel_frames", "wh_log_mel", "wh_encode", "wh_decode_greedy", "wh_decode_greedy_batch", "wh_transcribe_batch",
            "wh_transcribe_batch_device", "wh_longform_plan", "wh_transcribe_longform", "wh_profile_enable",
            "wh_profile_get", "wh_synthetic_weights", "wh_e4m3_quantize", "wh_e4m3_dequantize", "wh_abi_version",
            "wh_device_count")
@@ -93,6 +93,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.wh_log_mel.argtypes = [vp, f32p, C.c_size_t, f32p, C.c_size_t, szp]
     L.wh_encode.argtypes = [vp, f32p, f32p]
     L.wh_decode_greedy.argtypes = [vp, C.POINTER(WhDecodeParams), i64p, C.c_size_t, szp, f32p, C.c_size_t]
+    L.wh_decode_greedy_batch.argtypes = [vp, C.POINTER(WhDecodeParams), i64p, C.c_size_t, szp, C.c_size_t, szp, f32p, C.c_size_t]
     L.wh_transcribe_batch.argtypes = [vp, C.POINTER(WhClip), C.c_size_t, C.POINTER(WhDecodeParams), i64p, szp]
     L.wh_transcribe_batch_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(WhDecodeParams), i64p, szp]
     L.wh_longform_plan.argtypes = [C.c_size_t, C.c_double, C.c_double, szp, C.c_size_t, szp]
@@ -239,6 +240,24 @@ class Context:
                                               _f32(logits) if want_logits else None, params.max_new_tokens))
         nt = int(n.value)
         return toks[:nt].copy(), (logits[: nt - len(params.prompt)].copy() if want_logits else None)
+
+    def greedy_decode_resident_batch(self, params: DecodeParams, want_logits: bool = False
+                                     ) -> Tuple[List[np.ndarray], Optional[List[np.ndarray]]]:
+        """Parity harness: greedy_decode_with_past over every clip whose encoder states are resident (the last
+        transcribe_batch / run_encoder), decoded as ONE batch, optionally with the logits rows of every clip."""
+        p, keep = params.to_c()
+        cap = len(params.prompt) + params.max_new_tokens
+        nb = self.max_batch
+        toks = np.zeros((nb, cap), np.int64)
+        n = (C.c_size_t * nb)()
+        got = C.c_size_t(0)
+        logits = np.zeros((nb, params.max_new_tokens, self.model.dims.vocab), np.float32) if want_logits else None
+        self._check(self.lib.wh_decode_greedy_batch(self.h, C.byref(p), _i64(toks), cap, n, nb, C.byref(got),
+                                                    _f32(logits) if want_logits else None, params.max_new_tokens))
+        k = int(got.value)
+        out = [toks[i, : n[i]].copy() for i in range(k)]
+        lg = [logits[i, : n[i] - len(params.prompt)] for i in range(k)] if want_logits else None
+        return out, lg
 
     # --- fused batch entries ----------------------------------------------------------------------
     def transcribe_batch(self, clips: Sequence[np.ndarray], params: DecodeParams) -> List[np.ndarray]:

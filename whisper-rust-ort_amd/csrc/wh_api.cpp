@@ -188,6 +188,15 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
     return WH_OK;
 }
 
+void drop_step_graph(wh_ctx* c) {
+    if (c->step_exec && c->stream) hipStreamSynchronize(c->stream);  // an error path may have left replays in flight
+    if (c->step_exec) hipGraphExecDestroy(c->step_exec);
+    if (c->step_graph) hipGraphDestroy(c->step_graph);
+    c->step_exec = nullptr;
+    c->step_graph = nullptr;
+    c->step_key = wh_ctx::StepKey();
+}
+
 void pack_mask(const int64_t* a, size_t na, const int64_t* b, size_t nb, int vocab, std::vector<unsigned>& out) {
     out.assign((size_t)vocab / 32 + 1, 0u);
     for (size_t i = 0; i < na; i++)
@@ -240,7 +249,8 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     if (logits_out) {
         const size_t need = (size_t)nb * logits_rows * D.vocab;
         if (need > c->logits_cap) {
-            if (c->logits) hipFree(c->logits);
+            drop_step_graph(c);  // the captured step holds the old buffer's address
+            if (c->logits) CTX_HIP(c, hipFree(c->logits));
             c->logits = nullptr;
             c->logits_cap = 0;
             CTX_HIP(c, hipMalloc((void**)&c->logits, need * 4));
@@ -266,7 +276,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
         wh_launch_gemm(s, prec, false, g);
         if (f8) {  // bf16 projection → e4m3 codes, one scale per (layer, K|V, clip, head)
             const long planes = (long)D.dec_layers * 2 * nb;
-            hipMemsetAsync(c->kv_amax, 0, planes * D.n_heads * 4, s);
+            CTX_HIP(c, hipMemsetAsync(c->kv_amax, 0, planes * D.n_heads * 4, s));
             wh_launch_kv_quant(s, c->cross_kv, (unsigned*)c->kv_amax, c->cross_kv8, planes, (int)S, (int)d, D.n_heads);
         }
     }
@@ -391,30 +401,46 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     // Run per token in the reference).
     for (int step = 0; step < std::min(P, total_pos); step++) launch_step(step >= P - 1, true);
     const int remaining = total_pos - P;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t gexec = nullptr;
     // with event timing on: every position is launched eagerly (stride 0/1), or only every stride-th one
     // (sampled live timing) while the others replay the graph
     const int stride = c->prof ? c->prof_stride : 0;
     const bool use_graph = remaining > 1 && !c->no_graph && (!c->prof || stride > 1);
     if (use_graph) {
-        c->capturing = true;   // no event records inside the captured step
-        hipError_t ce = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-        if (ce == hipSuccess) {
-            launch_step(true, false);
-            ce = hipStreamEndCapture(s, &graph);
+        wh_ctx::StepKey key;
+        key.nb = nb; key.n_prompt = P; key.eot = (int)p->eot; key.n_forced = (int)p->n_forced;
+        key.logits_rows = (int)logits_rows; key.d_logits = d_logits;
+        if (!c->step_exec || !(c->step_key == key)) {
+            drop_step_graph(c);   // nothing of it is in flight: every call ends with a stream synchronisation
+            c->capturing = true;  // no event records inside the captured step
+            hipGraph_t graph = nullptr;
+            hipError_t ce = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+            if (ce == hipSuccess) {
+                launch_step(true, false);
+                ce = hipStreamEndCapture(s, &graph);
+            }
+            c->capturing = false;
+            if (ce != hipSuccess) {
+                if (graph) hipGraphDestroy(graph);
+                return fail(c, WH_ERR_HIP, "graph capture of the decode step failed: %s", hipGetErrorString(ce));
+            }
+            hipGraphExec_t gexec = nullptr;
+            ce = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+            if (ce != hipSuccess) {
+                hipGraphDestroy(graph);
+                return fail(c, WH_ERR_HIP, "hipGraphInstantiate of the decode step failed: %s", hipGetErrorString(ce));
+            }
+            c->step_graph = graph;
+            c->step_exec = gexec;
+            c->step_key = key;
         }
-        c->capturing = false;
-        if (ce != hipSuccess) return fail(c, WH_ERR_HIP, "graph capture of the decode step failed: %s", hipGetErrorString(ce));
-        CTX_HIP(c, hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
     }
     for (int r = 0; r < remaining; r++) {
         const bool sampled = c->prof && stride > 1 && (r % stride) == stride / 2;
         if (use_graph && !sampled) {
-            hipError_t ge = hipGraphLaunch(gexec, s);
+            hipError_t ge = hipGraphLaunch(c->step_exec, s);
             if (ge != hipSuccess) {
-                hipGraphExecDestroy(gexec);
-                hipGraphDestroy(graph);
+                hipStreamSynchronize(s);
+                drop_step_graph(c);
                 return fail(c, WH_ERR_HIP, "hipGraphLaunch failed: %s", hipGetErrorString(ge));
             }
         } else {
@@ -425,18 +451,12 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
         if ((gen & 15) == 15 && r + 1 < remaining && p->n_forced == 0) {
             hipError_t e1 = hipMemcpyAsync(done_h.data(), c->done, nb * 4, hipMemcpyDeviceToHost, s);
             hipError_t e2 = hipStreamSynchronize(s);
-            if (e1 != hipSuccess || e2 != hipSuccess) {
-                if (use_graph) { hipGraphExecDestroy(gexec); hipGraphDestroy(graph); }
+            if (e1 != hipSuccess || e2 != hipSuccess)
                 return fail(c, WH_ERR_HIP, "decode: polling the done flags failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
-            }
             bool all = true;
             for (int b = 0; b < nb; b++) all = all && done_h[b];
             if (all) break;
         }
-    }
-    if (use_graph) {
-        hipGraphExecDestroy(gexec);
-        hipGraphDestroy(graph);
     }
     CTX_HIP(c, hipEventRecord(c->ev[3], s));
     // results
@@ -661,6 +681,7 @@ void wh_ctx_free(wh_ctx* c) {
     if (!c) return;
     hipSetDevice(c->m->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    drop_step_graph(c);
     for (int g = 0; g < WH_KG_COUNT; g++)
         for (auto& e : c->prof_events[g]) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : c->ev)
@@ -810,6 +831,34 @@ int wh_decode_greedy(wh_ctx* c, const wh_decode_params* p, int64_t* tokens_out, 
     const double t0 = now_s();
     CTX_HIP(c, hipEventRecord(c->ev[2], c->stream));
     rc = run_decode(c, 1, p, tokens_out, cap_tokens, n_tokens_out, logits_out, p->max_new_tokens);
+    if (rc) return rc;
+    float ms = 0;
+    hipEventElapsedTime(&ms, c->ev[2], c->ev[3]);
+    const double d2h = c->timing.d2h_s;
+    c->timing = wh_timing{};
+    c->timing.decode_s = ms * 1e-3;
+    c->timing.d2h_s = d2h;
+    c->timing.total_s = now_s() - t0;
+    prof_collect(c);
+    return WH_OK;
+}
+
+int wh_decode_greedy_batch(wh_ctx* c, const wh_decode_params* p, int64_t* tokens_out, size_t cap_tokens, size_t* n_tokens_out,
+                           size_t cap_clips, size_t* n_clips_out, float* logits_out, size_t cap_logits_rows) {
+    if (!c) return WH_ERR_ARG;
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    if (!c->have_enc) return fail(c, WH_ERR_STATE, "Missing cached decoder input: encoder states (call wh_transcribe_batch or wh_encode first)");
+    const int nb = c->enc_batch;
+    if (n_clips_out) *n_clips_out = (size_t)nb;
+    if (!tokens_out || !n_tokens_out || cap_clips < (size_t)nb || cap_tokens < p->n_prompt + p->max_new_tokens)
+        return fail(c, WH_ERR_ARG, "tokens_out needs %d rows of capacity n_prompt + max_new_tokens", nb);
+    if (logits_out && cap_logits_rows < p->max_new_tokens) return fail(c, WH_ERR_ARG, "logits_out needs max_new_tokens rows per clip");
+    CTX_HIP(c, hipSetDevice(c->m->device));
+    prof_reset(c);
+    const double t0 = now_s();
+    CTX_HIP(c, hipEventRecord(c->ev[2], c->stream));
+    rc = run_decode(c, nb, p, tokens_out, cap_tokens, n_tokens_out, logits_out, logits_out ? cap_logits_rows : 0);
     if (rc) return rc;
     float ms = 0;
     hipEventElapsedTime(&ms, c->ev[2], c->ev[3]);

@@ -238,8 +238,7 @@ void wh_launch_enc_attn(hipStream_t s, int prec, const void* qk, const void* vT,
     dim3 grid(((S + 127) / 128) * n_heads * n_clips);
     if (prec == WH_PREC_F32) {
         const size_t sm = (size_t)2 * 2 * 64 * (64 + 4) * 4;  // 69.6 KB: above the default dynamic-LDS limit
-        static bool once = (hipFuncSetAttribute((const void*)k_enc_attn<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm), true);
-        (void)once;
+        wh_ensure_dyn_lds((const void*)k_enc_attn<float>, sm);
         hipLaunchKernelGGL(k_enc_attn<float>, grid, dim3(256), sm, s, (const float*)qk, (const float*)vT, (float*)out, S, d, ldv, n_heads);
     } else {
         const size_t sm = (size_t)2 * 2 * 64 * (64 + 8) * 2;

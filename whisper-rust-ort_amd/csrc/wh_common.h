@@ -181,4 +181,8 @@ __device__ __host__ __forceinline__ float ord2f(unsigned u) {
     } while (0)
 
 int wh_fail_hip(hipError_t e, const char* what, const char* file, int line);
+// Dynamic-LDS opt-in above the 64 KB default, once per (current device, kernel, size): hipFuncSetAttribute applies to the
+// device that is current when it is called, so a process that opens several devices needs it on each.  A failure is
+// recorded through wh_set_error (the launch that follows then fails and surfaces at the call's hipGetLastError).
+bool wh_ensure_dyn_lds(const void* kernel, size_t bytes);
 void wh_set_error(const char* fmt, ...);

@@ -934,18 +934,11 @@ __global__ __launch_bounds__(256) void k_dec_cross_attn(const T* __restrict__ q,
     }
 }
 
-// raise a kernel's dynamic-LDS limit once per (kernel, size)
+// raise a kernel's dynamic-LDS limit once per (device, kernel, size)
 template <typename K>
 void set_max_smem(K kernel, size_t bytes) {
     if (bytes <= 48 * 1024) return;
-    static std::mutex mu;
-    static std::unordered_map<const void*, size_t> done;
-    std::lock_guard<std::mutex> lk(mu);
-    size_t& cur = done[(const void*)kernel];
-    if (bytes > cur) {
-        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        cur = bytes;
-    }
+    wh_ensure_dyn_lds((const void*)kernel, bytes);
 }
 
 template <typename T, typename TO, int NW, typename TW>

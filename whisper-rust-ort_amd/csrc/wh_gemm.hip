@@ -250,8 +250,7 @@ void launch_gemm_t(hipStream_t s, const GemmArgs& g) {
     if (blocks128 >= 192) {
         dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, g.batch);
         const size_t sm = (size_t)2 * (128 + 128) * LDK * sizeof(T);
-        static bool once = (hipFuncSetAttribute((const void*)k_gemm<T, TO, 128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm), true);
-        (void)once;
+        wh_ensure_dyn_lds((const void*)k_gemm<T, TO, 128, 128>, sm);
         hipLaunchKernelGGL((k_gemm<T, TO, 128, 128>), grid, dim3(256), sm, s, g);
     } else {
         dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, g.batch);

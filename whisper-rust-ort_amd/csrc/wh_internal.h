@@ -126,6 +126,19 @@ struct wh_ctx {
     int tok_ld = 0;
     int mpad = 16;              // row pitch of the k-slab-major decode activations (multiple of 16)
     int cross_splits = 1;
+    // The captured decode step, kept across calls: every kernel argument the step bakes in is either a fixed workspace
+    // address or one of the values below, so a call with the same key replays the instantiated graph as it is.
+    // Destroyed in wh_ctx_free (after the stream has drained) or when the key changes.
+    struct StepKey {
+        int nb = 0, n_prompt = 0, eot = 0, n_forced = 0, logits_rows = 0;
+        const float* d_logits = nullptr;
+        bool operator==(const StepKey& o) const {
+            return nb == o.nb && n_prompt == o.n_prompt && eot == o.eot && n_forced == o.n_forced && logits_rows == o.logits_rows &&
+                   d_logits == o.d_logits;
+        }
+    } step_key;
+    hipGraph_t step_graph = nullptr;
+    hipGraphExec_t step_exec = nullptr;
 };
 
 // Linear weights that arrived already quantised (F8_E4M3 + "<name>_scale" in model.safetensors, written by

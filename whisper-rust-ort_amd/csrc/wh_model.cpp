@@ -17,6 +17,8 @@
 
 #include <algorithm>
 #include <fstream>
+#include <map>
+#include <mutex>
 #include <sstream>
 #include <thread>
 
@@ -35,6 +37,23 @@ void wh_set_error(const char* fmt, ...) {
     g_err = buf;
 }
 const std::string& wh_global_error() { return g_err; }
+
+bool wh_ensure_dyn_lds(const void* kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> done;  // (device, kernel) -> largest size set
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t& cur = done[{dev, kernel}];
+    if (bytes <= cur) return true;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        wh_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) failed on device %d: %s", bytes, dev, hipGetErrorString(e));
+        return false;
+    }
+    cur = bytes;
+    return true;
+}
 int wh_fail_hip(hipError_t e, const char* what, const char* file, int line) {
     wh_set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
     return WH_ERR_HIP;
@@ -143,13 +162,18 @@ void wh_synth_weights(const wh_dims& c, uint64_t seed, std::vector<float>& out) 
             continue;
         }
         float offv = 0.0f, amp;
-        if (ends_with(name, "layer_norm.weight")) { offv = 1.0f; amp = 0.1f; }
+        // modelspec.value_rule: scales under which a random-weight model decodes non-degenerate greedy streams
+        if (name == "model.decoder.layer_norm.weight") { offv = 2.0f; amp = 0.2f; }
+        else if (ends_with(name, "layer_norm.weight")) { offv = 1.0f; amp = 0.1f; }
         else if (ends_with(name, ".bias")) amp = 0.1f;
-        else if (ends_with(name, "embed_tokens.weight")) amp = 0.2f;
+        else if (ends_with(name, "embed_tokens.weight")) amp = 0.05f;
         else if (ends_with(name, "decoder.embed_positions.weight")) amp = 0.05f;
         else {
             size_t fan_in = n / (size_t)e.second[0];
-            amp = (float)sqrt(3.0 / (double)fan_in);
+            double gain = 1.0;
+            if (name.rfind("model.decoder.", 0) == 0 && (ends_with(name, "out_proj.weight") || ends_with(name, "fc2.weight"))) gain = 4.0;
+            else if (ends_with(name, "q_proj.weight") || ends_with(name, "k_proj.weight")) gain = 2.5;
+            amp = (float)(sqrt(3.0 / (double)fan_in) * gain);
         }
         const float scale = amp / 8388608.0f;
         const uint64_t key = fnv1a64(name) ^ (seed * GOLD);

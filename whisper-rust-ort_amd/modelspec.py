@@ -155,18 +155,36 @@ def sinusoid_positions(length: int, channels: int) -> np.ndarray:
     return np.concatenate([np.sin(st), np.cos(st)], axis=1).astype(np.float32)
 
 
+# Scales chosen so that a random-weight model still behaves like a language model under greedy decoding
+# (SURVEY §7 hard part 1): with unit-gain layers and a large tied embedding the residual stream is dominated
+# by the input token's own embedding, the tied LM head then picks that token again and every free-running
+# stream degenerates into one repeated id.  Small embeddings, residual-branch gain 4 in the decoder, q/k
+# projections x2.5 (peaked, context-dependent attention) and a final-LayerNorm gain of 2 (logit std ~1.3) give
+# ~26 distinct ids per 48 generated tokens at whisper-base size with top-1 margins >= 1e-2, while two f32
+# implementations (this repo's oracle vs HF eager) still agree to ~1e-5 on the logits.  q/k x3 is already in a
+# chaotic regime: near-one-hot softmaxes amplify f32 summation-order noise to ~1e-3 on the logits.
+RES_GAIN, QK_GAIN, FINAL_LN_GAIN = 4.0, 2.5, 2.0
+
+
 def value_rule(name: str, shape: Tuple[int, ...]) -> Tuple[float, float]:
     """(offset, amplitude): value = offset + amplitude * U[-1,1)."""
+    if name == "model.decoder.layer_norm.weight":
+        return FINAL_LN_GAIN, 0.2
     if name.endswith("layer_norm.weight"):
         return 1.0, 0.1
     if name.endswith(".bias"):
         return 0.0, 0.1
     if name.endswith("embed_tokens.weight"):
-        return 0.0, 0.2
+        return 0.0, 0.05
     if name.endswith("decoder.embed_positions.weight"):
         return 0.0, 0.05
     fan_in = int(np.prod(shape[1:]))
-    return 0.0, float(np.float32(math.sqrt(3.0 / fan_in)))
+    gain = 1.0
+    if name.startswith("model.decoder.") and (name.endswith("out_proj.weight") or name.endswith("fc2.weight")):
+        gain = RES_GAIN
+    elif name.endswith("q_proj.weight") or name.endswith("k_proj.weight"):
+        gain = QK_GAIN
+    return 0.0, float(np.float32(math.sqrt(3.0 / fan_in) * gain))
 
 
 def synth_tensor(name: str, shape: Tuple[int, ...], seed: int) -> np.ndarray:
