@@ -17,6 +17,8 @@
 //   - per-clip batched products via blockIdx.z strides (V^T projection).
 // It stands in for ONNX Runtime's MLAS GEMM/Conv nodes behind run_encoder
 // (reference src/main.rs:698-707) and the step-0 cross-attention K/V projection (:771-787).
+#include <stdlib.h>
+
 #include "wh_common.h"
 #include "wh_kernels.h"
 
@@ -41,7 +43,18 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int fl = lane & 15, fg = lane >> 4;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one, each XCD has its
+    // own L2): linear id b runs tile (b % 8) * chunk + b / 8, so one XCD walks a CONTIGUOUS run of tiles, n fastest —
+    // the column tiles that share an activation row panel follow each other on one L2 and the panel leaves HBM once
+    // instead of once per XCD (bijective for any tile count; placement only affects speed, never results).
+    const int nbn = (g.N + BN - 1) / BN;
+    const int total = nbn * ((g.M + BM - 1) / BM);
+    int tile = blockIdx.x;
+    {
+        const int q = total >> 3, r = total & 7, xcd = tile & 7, idx = tile >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
     const long z = blockIdx.z;
     const T* A = (const T*)g.A + z * g.a_zs;
     const T* W = (const T*)g.W + z * g.w_zs;
@@ -248,12 +261,12 @@ void launch_gemm_t(hipStream_t s, const GemmArgs& g) {
     const long blocks128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;
     constexpr int LDK = Tile<T>::LDK;
     if (blocks128 >= 192) {
-        dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, g.batch);
+        dim3 grid(((g.N + 127) / 128) * ((g.M + 127) / 128), 1, g.batch);
         const size_t sm = (size_t)2 * (128 + 128) * LDK * sizeof(T);
         wh_ensure_dyn_lds((const void*)k_gemm<T, TO, 128, 128>, sm);
         hipLaunchKernelGGL((k_gemm<T, TO, 128, 128>), grid, dim3(256), sm, s, g);
     } else {
-        dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, g.batch);
+        dim3 grid(((g.N + 63) / 64) * ((g.M + 63) / 64), 1, g.batch);
         const size_t sm = (size_t)2 * (64 + 64) * LDK * sizeof(T);
         hipLaunchKernelGGL((k_gemm<T, TO, 64, 64>), grid, dim3(256), sm, s, g);
     }
@@ -262,6 +275,11 @@ void launch_gemm_t(hipStream_t s, const GemmArgs& g) {
 }  // namespace
 
 void wh_launch_gemm(hipStream_t s, int prec, bool out_f32, const GemmArgs& g) {
+    static const bool use8 = getenv("WH_GEMM8") == nullptr || atoi(getenv("WH_GEMM8")) != 0;   // WH_GEMM8=0: A/B against k_gemm
+    if (prec != WH_PREC_F32 && use8 && wh_gemm8_applicable(g)) {
+        wh_launch_gemm8(s, out_f32, g);
+        return;
+    }
     if (prec == WH_PREC_F32) {
         launch_gemm_t<float, float>(s, g);
     } else {

@@ -1,0 +1,319 @@
+// wh_gemm8.hip — the encoder-side bf16 GEMM for gfx950: 8 waves, 256 x {128, 256} x 32 tiles, operands streamed
+// global -> LDS by the LDS-DMA path (global_load_lds_dwordx4) through a ring of slots with counted waits.
+//
+//   C[m][n] = act( wscale[n] * sum_k A[m][k] * W[n][k] + bias ) + R[m][n]          (same contract as k_gemm, wh_gemm.hip)
+//
+// It stands in for ONNX Runtime's MLAS GEMM / Conv nodes behind run_encoder (reference src/main.rs:698-707) and the
+// step-0 cross-attention K/V projection (:771-787) wherever the problem has at least one full tile; k_gemm keeps the
+// small shapes and the exact-f32 mode.
+//
+// Structure:
+//   * slot = A tile [256 rows][32 k] + W tile [BN rows][32 k], 64-byte rows.  A wave-instruction of the LDS-DMA writes
+//     1 KiB = 16 whole rows, lane i -> row i/4, 16-byte chunk i%4.  LDS is written linearly by construction, so the bank
+//     swizzle sits on the SOURCE side: LDS chunk p of row r holds k-chunk p ^ swz(r); the permutation stays inside the
+//     row's own 64 bytes, so global reads stay whole lines.  Fragment reads (ds_read_b128: lane l -> row l & 15,
+//     k-chunk l >> 4) apply the same XOR and are conflict-free (see swz()).
+//   * k-step t:  wait until this wave's slot-t loads have landed (counted s_waitcnt vmcnt: the newer stages stay in
+//     flight), raw s_barrier (every wave's slot-t data is there, and every wave has finished reading slot t-1), issue
+//     the stage that reuses the slot step t-1 read, then the MFMAs (16x16x32 bf16) on slot t.  One barrier per k-step,
+//     never vmcnt(0) inside the loop.
+//   * two geometries.  BN = 256: waves 2 x 4, 128 x 64 per wave, 4 slots x 32 KiB, one workgroup per CU, fragments
+//     double-buffered in registers (241 VGPRs) — the default: half the L2 -> LDS traffic per flop.  BN = 128: waves 4 x 2,
+//     64 x 64 per wave, 3 slots x 24 KiB = 72 KiB, two workgroups per CU (116 VGPRs) — used for the GELU GEMM, whose
+//     VALU-heavy epilogue a second workgroup hides under its own MFMAs.
+//     Measured on MI355X at 256 clips (tools/gemm8_ablate.hip, which also times ablated variants): main loop alone
+//     ~1.0 PF/s in either geometry (BN = 128 is bound by the L2 -> LDS stream, 12-14 TB/s chip-wide; BN = 256 by the
+//     barrier-paced MFMA phases), epilogue +50...100 %: a CU's vector-memory path is shared by the LDS-DMA loads, the
+//     residual reads and the stores, so a co-resident workgroup's loads queue behind the other's store burst — staggering
+//     the two workgroups of a CU by half a tile changed nothing (measured), and was dropped.
+//   * the weight tile is the MFMA row operand: a lane ends up with 4 consecutive n of one output row, which makes bias /
+//     channel-scale loads and the LDS staging writes 16-byte.
+//   * epilogue: each wave parks 32 rows of its sub-tile at a time in its own 8.5 KiB of the (now idle) ring and stores
+//     them row-contiguously with 16 bytes per lane in either output type (8-byte-per-lane bf16 stores ran at 3 TB/s,
+//     16-byte ones at 5 TB/s); the f32 residual is read the same way.  No workgroup barrier in the epilogue.
+//   * XCD-aware tile order as in k_gemm: one XCD walks a contiguous run of tiles, n fastest, so the column tiles that share
+//     an activation row panel reuse it from that XCD's L2.
+#include "wh_common.h"
+#include "wh_kernels.h"
+
+namespace {
+
+constexpr int BM = 256, BK = 32;
+constexpr int ROWB = BK * 2;                        // 64 bytes per LDS row
+constexpr int EP_PITCH = 68;                        // floats per staged output row (64 + 4: conflict-free both ways)
+constexpr int EP_ROWS = 32;                         // rows of a wave's sub-tile staged per pass (8.5 KiB per wave)
+
+template <int BN> struct Geo {
+    static constexpr int WN = BN / 64, WM = 8 / WN;              // waves along n / m
+    static constexpr int TM = BM / WM / 16, TN = 4;              // 16 x 16 MFMA tiles per wave
+    static constexpr int SLOT_A = BM * ROWB, SLOT = SLOT_A + BN * ROWB;
+    static constexpr int NSLOT = BN == 128 ? 3 : 4;                // ring slots: one being read, the others in flight
+    static constexpr int W_INSTR = BN / 128;                     // LDS-DMA instructions of W per wave and stage
+    static constexpr int PER_STAGE = 2 + W_INSTR;                // ... of A and W together
+    static constexpr int WAVES_PER_SIMD = BN == 128 ? 4 : 2;
+    static constexpr bool PIPE = BN == 256;                      // fragment double buffering needs ~240 VGPRs: one workgroup per CU only
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+// LDS chunk (16 bytes) p of tile row r holds k-chunk p ^ swz(r): with 64-byte rows a 256-byte bank row holds 4 tile rows
+// and the 16-lane service groups of ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) mix the k-chunks c and c+1 of
+// row quadruples {0,3} and {1,2}: XOR-ing bit 1 of the chunk with bit 3 of the row makes every group hit 16 distinct slots.
+__device__ __forceinline__ int swz(int row) { return (row >> 2) & 2; }
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ void store8(float* p, const f32x4& a, const f32x4& b) {   // 8 consecutive outputs
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+__device__ __forceinline__ void store8(bf16* p, const f32x4& a, const f32x4& b) {
+    *reinterpret_cast<bf16x8*>(p) = bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+}
+
+// ABL (tools/gemm8_ablate.hip only; 0 in the library): 1 = no MFMA (fragment reads kept), 2 = no LDS-DMA inside the loop,
+// 4 = no epilogue, 8 = no fragment reads and no MFMA (loads + barriers only), 16 = epilogue without its global stores
+template <typename TO, int BN, int ABL = 0>
+__global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs g) {
+    typedef Geo<BN> G;
+    constexpr int TM = G::TM, TN = G::TN, NSLOT = G::NSLOT, SLOT = G::SLOT, SLOT_A = G::SLOT_A;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / G::WN, wn = wave % G::WN;
+    const int fl = lane & 15, fg = lane >> 4;
+    const int nk = g.K / BK;
+
+    const int nbn = (g.N + BN - 1) / BN;
+    const int total = nbn * ((g.M + BM - 1) / BM);
+    int tile = blockIdx.x;
+    {
+        const int q = total >> 3, r = total & 7, xcd = tile & 7, idx = tile >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
+    const long z = blockIdx.z;
+    const bf16* A = (const bf16*)g.A + z * g.a_zs;
+    const bf16* W = (const bf16*)g.W + z * g.w_zs;
+
+    // per-lane source pointers of this wave's share of a stage: one wave-instruction = 1 KiB = 16 rows x 64 bytes,
+    // lane i -> row i / 4, chunk i % 4; 2 instructions of A (32 rows), 1 or 2 of W (16 or 32 rows) per wave
+    const int rl = lane >> 2, ps = lane & 3;
+    const bf16* a_src[2];
+    const bf16* w_src[G::W_INSTR];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int row = wave * 32 + j * 16 + rl;
+        int m = m0 + row;
+        if (m > g.M - 1) m = g.M - 1;
+        a_src[j] = A + (long)(m / g.m_per) * g.a_bs + (long)(m % g.m_per) * g.lda + ((ps ^ swz(row)) << 3);
+    }
+#pragma unroll
+    for (int j = 0; j < G::W_INSTR; j++) {
+        const int row = wave * (16 * G::W_INSTR) + j * 16 + rl;
+        int n = n0 + row;
+        if (n > g.N - 1) n = g.N - 1;
+        w_src[j] = W + (long)n * g.ldw + ((ps ^ swz(row)) << 3);
+    }
+    auto stage = [&](int slot, int kt) {
+        char* base = smem + slot * SLOT;
+#pragma unroll
+        for (int j = 0; j < 2; j++) glds16(a_src[j] + (long)kt * BK, base + (wave * 32 + j * 16) * ROWB);
+#pragma unroll
+        for (int j = 0; j < G::W_INSTR; j++) glds16(w_src[j] + (long)kt * BK, base + SLOT_A + (wave * (16 * G::W_INSTR) + j * 16) * ROWB);
+    };
+
+    f32x4 acc[TM][TN];   // [m tile][n tile]
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    // fragment byte offsets inside a slot (row-local swizzle: rows of a 16-row tile start at a multiple of 16)
+    const int ch = (fg ^ swz(fl)) << 4;
+    const int a_off = (wm * (TM * 16) + fl) * ROWB + ch;
+    const int w_off = SLOT_A + (wn * 64 + fl) * ROWB + ch;
+
+    // Software pipeline (BN = 256): the fragments of k-step t+1 are read from LDS into a second register set while the
+    // MFMAs of k-step t run on the first, so a wave does not stand between a barrier and its MFMAs waiting for ds_reads.
+    //   top of step t:  stage t+1 has landed (counted wait) | barrier | issue stage t+NSLOT into the slot whose
+    //   fragments were read during step t-1 | read fragments of t+1 | MFMAs of t.
+    // BN = 128 (two workgroups per CU, 128 VGPRs each) reads the fragments of step t right before its MFMAs.
+    bf16x8 af[G::PIPE ? 2 : 1][TM], wf[G::PIPE ? 2 : 1][TN];
+    auto read_frags = [&](int set, int kt) {
+        const char* sb = smem + (kt % NSLOT) * SLOT;
+#pragma unroll
+        for (int i = 0; i < TM; i++) af[set][i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 16 * ROWB);
+#pragma unroll
+        for (int j = 0; j < TN; j++) wf[set][j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 16 * ROWB);
+    };
+    auto mfmas = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                if (!(ABL & 1)) mma16(acc[i][j], wf[set][j], af[set][i]);   // D rows = n, cols = m
+                else asm volatile("" :: "v"(wf[set][j]), "v"(af[set][i]));
+            }
+    };
+    // wait until this wave's stage `kt` has landed: the younger stages issued so far (at most `cap`) stay outstanding.
+    // vmcnt retires in issue order, so "at most newer * PER_STAGE outstanding" == "stage kt and everything older is done".
+    auto wait_stage = [&](int kt, int cap) {
+        const int newer = (ABL & 2) ? 0 : min(cap, nk - 1 - kt);
+        if (newer >= 3) wait_vm<3 * G::PER_STAGE>();
+        else if (newer == 2) wait_vm<2 * G::PER_STAGE>();
+        else if (newer == 1) wait_vm<G::PER_STAGE>();
+        else wait_vm<0>();
+    };
+    if (G::PIPE) {
+#pragma unroll
+        for (int t = 0; t < NSLOT; t++)
+            if (t < nk) stage(t, t);
+        wait_stage(0, NSLOT - 1);           // the whole ring was just issued: slots 1 .. NSLOT-1 may still be in flight
+        __builtin_amdgcn_s_barrier();
+        if (!(ABL & 8)) read_frags(0, 0);
+        // two k-steps per iteration so the register sets are named statically
+        for (int kt = 0; kt < nk; kt += 2) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int t = kt + h;
+                if (t >= nk) break;
+                if (t + 1 < nk) {
+                    wait_stage(t + 1, NSLOT - 2);       // in flight here: stages t+1 .. t+NSLOT-1 (t+NSLOT is issued below)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads of step t have left LDS
+                    __builtin_amdgcn_s_barrier();       // stage t+1 visible to all; every wave has read the fragments of t
+                    if (t + NSLOT < nk) {               // slot of stage t is free again
+                        if (!(ABL & 2)) stage(t % NSLOT, t + NSLOT);
+                        else asm volatile("s_nop 0" ::: "memory");
+                    }
+                    if (!(ABL & 8)) read_frags((h ^ 1) & (G::PIPE ? 1 : 0), t + 1);
+                }
+                if (!(ABL & 8)) mfmas(h & (G::PIPE ? 1 : 0));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NSLOT - 1; t++)
+            if (t < nk) stage(t, t);
+        for (int kt = 0; kt < nk; kt++) {
+            wait_stage(kt, NSLOT - 2);          // in flight: stages kt .. kt+NSLOT-2
+            __builtin_amdgcn_s_barrier();       // stage kt visible to all; every wave has consumed the fragments of kt-1
+            if (kt + NSLOT - 1 < nk) {
+                if (!(ABL & 2)) stage((kt + NSLOT - 1) % NSLOT, kt + NSLOT - 1);
+                else asm volatile("s_nop 0" ::: "memory");
+            }
+            if (ABL & 8) continue;
+            read_frags(0, kt);
+            mfmas(0);
+        }
+    }
+    __builtin_amdgcn_s_barrier();   // every wave is done with the ring: it becomes the output staging area
+    if ((ABL & 4) && g.M > 0) {     // keep the accumulators alive, store nothing
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) asm volatile("" :: "v"(acc[i][j]));
+        return;
+    }
+
+    // ---- epilogue: passes of 32 rows per wave through the wave's own 8.5 KiB of the idle ring ------------------------
+    float* stg = reinterpret_cast<float*>(smem) + wave * (EP_ROWS * EP_PITCH);
+    const int nw0 = n0 + wn * 64;            // first column of this wave's sub-tile
+    const int mw0 = m0 + wm * (TM * 16);
+    TO* C = (TO*)g.C + z * g.c_zs;
+    const float* R = g.R ? g.R + z * g.r_zs : nullptr;
+    const long nc0 = (long)(nw0 / g.n_per) * g.c_ns + (nw0 % g.n_per);   // n_per is a multiple of 64 or >= N (checked at launch)
+    f32x4 pb[TN], pw[TN];
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = nw0 + j * 16 + fg * 4;
+        pb[j] = f32x4{0, 0, 0, 0};
+        pw[j] = f32x4{1, 1, 1, 1};
+        if (n < g.N && g.bias_mode == 1) {
+            if (g.bias) pb[j] = *reinterpret_cast<const f32x4*>(g.bias + n);
+            if (g.wscale) pw[j] = *reinterpret_cast<const f32x4*>(g.wscale + n);
+        }
+    }
+    // row-contiguous read-back: 8 lanes x 8 columns per row, 8 rows per wave-instruction
+    const int c8 = (lane & 7) * 8, r8 = lane >> 3;
+    const int n_st = nw0 + c8;
+#pragma unroll
+    for (int pass = 0; pass < TM / 2; pass++) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ii++) {
+            const int i = pass * 2 + ii;
+            const int m = mw0 + i * 16 + fl;
+            float bm = 0.0f, wmul = 1.0f;
+            if (g.bias_mode == 2 && m < g.M) {
+                if (g.bias) bm = g.bias[m];
+                if (g.wscale) wmul = g.wscale[m];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = acc[i][j][e] * (pw[j][e] * wmul) + (pb[j][e] + bm);
+                if (g.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
+                }
+                *reinterpret_cast<f32x4*>(&stg[(ii * 16 + fl) * EP_PITCH + j * 16 + fg * 4]) = f32x4{v[0], v[1], v[2], v[3]};
+            }
+        }
+        // wave-private staging: the wave's own LDS writes are ordered before its reads by the lgkmcnt wait the compiler inserts
+        const int mp0 = mw0 + pass * EP_ROWS + r8;       // this lane's first row of the pass; its rows are mp0 + 8 * it
+        long mb = mp0 / g.m_per, mi = mp0 % g.m_per;     // row -> (block, row in block), advanced without dividing again
+#pragma unroll
+        for (int it = 0; it < EP_ROWS / 8; it++) {
+            const int lr = it * 8 + r8, m = mp0 + it * 8;
+            if (m < g.M && n_st < g.N) {
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(&stg[lr * EP_PITCH + c8]);
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(&stg[lr * EP_PITCH + c8 + 4]);
+                if (R) {
+                    const float* rp = R + mb * g.r_bs + mi * g.ldr + n_st;
+                    const f32x4 r0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp));  // read once
+                    const f32x4 r1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp + 4));
+                    v0 += r0;
+                    v1 += r1;
+                }
+                TO* cp = C + mb * g.c_bs + mi * g.ldc + nc0 + c8;
+                if (ABL & 16) asm volatile("" :: "v"(v0), "v"(v1));   // everything but the store
+                else if (n_st + 8 <= g.N) store8(cp, v0, v1);
+                else store4(cp, v0[0], v0[1], v0[2], v0[3]);          // N % 8 == 4: the last group holds 4 valid columns
+            }
+            mi += 8;
+            if (mi >= g.m_per) { mi -= g.m_per; mb += 1; }
+        }
+    }
+}
+
+template <typename TO, int BN>
+void launch8(hipStream_t s, const GemmArgs& g) {
+    typedef Geo<BN> G;
+    const size_t sm = (size_t)G::NSLOT * G::SLOT;
+    static_assert((size_t)8 * EP_ROWS * EP_PITCH * 4 <= (size_t)G::NSLOT * G::SLOT, "output staging must fit the ring");
+    dim3 grid(((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM), 1, g.batch);
+    wh_ensure_dyn_lds((const void*)k_gemm8<TO, BN>, sm);
+    hipLaunchKernelGGL((k_gemm8<TO, BN>), grid, dim3(512), sm, s, g);
+}
+
+}  // namespace
+
+bool wh_gemm8_applicable(const GemmArgs& g) {
+    // N tails are handled by clamping + masking in 8-column groups (a last group of 4); the column-plane mapping needs 64-column granularity;
+    // the row -> (block, row) walk of the epilogue advances by 8 rows at a time
+    return g.M >= BM && g.N >= 128 && (g.K % BK) == 0 && (g.N % 4) == 0 && (g.n_per >= g.N || (g.n_per % 64) == 0) && g.m_per >= 8;
+}
+
+void wh_launch_gemm8(hipStream_t s, bool out_f32, const GemmArgs& g) {
+    // measured per shape (tools/gemm8_ablate.hip): the GELU epilogue is VALU work that a second workgroup on the CU hides
+    // under its own MFMAs (fc1: 1.30 ms with BN = 128 against 1.43 ms); everything else is faster or equal with the larger
+    // tile's halved L2 -> LDS traffic
+    const bool wide = g.act == 0 && g.N >= 256;
+    if (out_f32) { if (wide) launch8<float, 256>(s, g); else launch8<float, 128>(s, g); }
+    else { if (wide) launch8<bf16, 256>(s, g); else launch8<bf16, 128>(s, g); }
+}

@@ -103,6 +103,9 @@ void wh_launch_mel_tokens(hipStream_t s, const float* src, long src_clip_stride,
                           int mode, int n_mels, int n_out, T* tok, long tok_clip_stride);
 
 void wh_launch_gemm(hipStream_t s, int prec, bool out_f32, const GemmArgs& g);
+// wh_gemm8.hip: the 8-wave LDS-DMA kernel (bf16 operands) for problems with at least one full 256 x 128 tile
+bool wh_gemm8_applicable(const GemmArgs& g);
+void wh_launch_gemm8(hipStream_t s, bool out_f32, const GemmArgs& g);
 void wh_launch_layernorm(hipStream_t s, int prec, const float* x, const float* w, const float* b, void* y, long rows,
                          int d);
 void wh_launch_enc_attn(hipStream_t s, int prec, const void* qk, const void* vT, void* out, int n_clips, int S, int d,
