@@ -76,7 +76,7 @@ def build_host(verbose: bool = False, force: bool = False) -> None:
         subprocess.check_call(cmd)
     src = os.path.join(HOST, "whisper_bench.cpp")
     if force or _stale(CLI, [src, OUT] + hdr):
-        cmd = [gxx, "-O2", "-std=c++17", "-Wall", "-pthread", "-o", CLI, src, "-L" + HERE, "-lwhisper_hip",
+        cmd = [gxx, "-O2", "-std=c++17", "-Wall", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", CLI, src, "-L" + HERE, "-lwhisper_hip",
                "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -5,9 +5,17 @@
 #include <dirent.h>
 #include <sys/stat.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
 #include <thread>
+
+#include <hip/hip_runtime_api.h>
 
 #include "../../include/whisper_hip.h"
 #include "wh_host.h"
@@ -28,6 +36,9 @@ struct Args {
     float chunk_length_s = 30.0f, overlap_s = 5.0f;
     // additive (GPU) flags
     int device = 0, max_batch = 16;
+    std::string devices;            // "0-7", "0,2,5": one model per listed device (default: --device)
+    int streams_per_gpu = 1;        // contexts (HIP streams) per device, one host thread each
+    int load_threads = 0;           // host threads that decode / synthesise audio ahead of the GPU (0 = min(16, cores))
     std::string precision = "bf16";
     size_t synthetic_clips = 0;
     uint64_t seed = 1000;
@@ -72,7 +83,8 @@ static bool parse_args(int argc, char** argv, Args& a) {
                    "[--task transcribe] [--max-new-tokens 128] [--warmup 0] [--limit-files 0] [--discovery-best-json F] "
                    "[--out-csv F] [--out-json F] [--out-summary-json F] [--intra-op N] [--inter-op N] [--write-txt] "
                    "[--tokenizer-json F] [--timestamps] [--chunk-parallelism N] [--chunk-length-s 30] [--overlap-s 5] "
-                   "[--device 0] [--precision bf16|f32|fp8] [--max-batch 16] [--synthetic-clips N] [--seed 1000]\n");
+                   "[--device 0] [--devices 0-7] [--streams-per-gpu 1] [--load-threads N] [--precision bf16|f32|fp8] [--max-batch 16] "
+                   "[--synthetic-clips N] [--seed 1000]\n");
             exit(0);
         } else {
             if (!need(i, argv[i], v, inl)) return false;
@@ -95,6 +107,9 @@ static bool parse_args(int argc, char** argv, Args& a) {
             else if (k == "--chunk-length-s") a.chunk_length_s = strtof(v.c_str(), nullptr);
             else if (k == "--overlap-s") a.overlap_s = strtof(v.c_str(), nullptr);
             else if (k == "--device") a.device = atoi(v.c_str());
+            else if (k == "--devices") a.devices = v;
+            else if (k == "--streams-per-gpu") a.streams_per_gpu = std::max(1, atoi(v.c_str()));
+            else if (k == "--load-threads") a.load_threads = atoi(v.c_str());
             else if (k == "--precision") a.precision = v;
             else if (k == "--max-batch") a.max_batch = atoi(v.c_str());
             else if (k == "--synthetic-clips") a.synthetic_clips = strtoull(v.c_str(), nullptr, 10);
@@ -168,21 +183,53 @@ static GenCfg load_generation_cfg(const std::string& path) {  // src/main.rs:650
     return g;
 }
 
-// deterministic in-memory clip (SURVEY §8d config 3 shape): three enveloped sinusoids + noise
+// deterministic in-memory clip (SURVEY §8d config 3 shape): three enveloped sinusoids (80-4000 Hz) + noise of standard
+// deviation 0.02, clipped to [-1, 1].  Built for speed, because the loader threads have to keep a GPU fed that transcribes
+// ~900 clips per second: oscillators and the 4 Hz raised-cosine envelope advance by complex rotation in float (re-seeded
+// from sin/cos every 1024 samples so the recurrence cannot drift), the noise is a 4-term Irwin-Hall sum (four 16-bit
+// uniforms from one splitmix64 draw, variance-matched to N(0,1)): ~3 ms per 30 s clip on one host core.
 static std::vector<float> synthetic_clip(uint64_t seed) {
     uint64_t st = seed * 0x9E3779B97F4A7C15ull + 1;
-    auto u01 = [&]() { st += 0x9E3779B97F4A7C15ull; uint64_t z = st; z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31; return (double)(z >> 11) / 9007199254740992.0; };
-    double fr[3], ph[3];
+    auto next64 = [&]() { st += 0x9E3779B97F4A7C15ull; uint64_t z = st; z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31; return z; };
+    auto u01 = [&]() { return (double)(next64() >> 11) / 9007199254740992.0; };
+    double fr[4], ph[4];
     for (int j = 0; j < 3; j++) { fr[j] = 80.0 + 3920.0 * u01(); ph[j] = 2 * M_PI * u01(); }
+    fr[3] = 4.0; ph[3] = 0.0;   // envelope 0.5 - 0.5 cos(2 pi 4 t)
     std::vector<float> x(WH_CLIP_SAMPLES);
+    float re[4], im[4], cr[4], ci[4];
+    for (int j = 0; j < 4; j++) { const double w = 2 * M_PI * fr[j] / 16000.0; cr[j] = (float)cos(w); ci[j] = (float)sin(w); }
+    const float nscale = 0.02f * 1.7320508f / 32768.0f;   // sum of 4 U(-1/2,1/2) has variance 1/3
     for (size_t i = 0; i < x.size(); i++) {
-        double t = (double)i / 16000.0, env = 0.5 - 0.5 * cos(2 * M_PI * 4.0 * t), s = 0;
-        for (int j = 0; j < 3; j++) s += sin(2 * M_PI * fr[j] * t + ph[j]);
-        double u1 = std::max(u01(), 1e-300), u2 = u01();
-        double v = 0.25 * s * env + 0.02 * sqrt(-2 * log(u1)) * cos(2 * M_PI * u2);
-        x[i] = (float)std::max(-1.0, std::min(1.0, v));
+        if ((i & 1023) == 0)
+            for (int j = 0; j < 4; j++) { const double a = 2 * M_PI * fr[j] * ((double)i / 16000.0) + ph[j]; re[j] = (float)cos(a); im[j] = (float)sin(a); }
+        const float s = im[0] + im[1] + im[2], env = 0.5f - 0.5f * re[3];
+        const uint64_t r = next64();
+        const int sum4 = (int)(r & 0xFFFF) + (int)((r >> 16) & 0xFFFF) + (int)((r >> 32) & 0xFFFF) + (int)(r >> 48) - 2 * 65535;
+        const float v = 0.25f * s * env + nscale * (float)sum4 * 0.5f;
+        x[i] = std::max(-1.0f, std::min(1.0f, v));
+        for (int j = 0; j < 4; j++) { const float nr = re[j] * cr[j] - im[j] * ci[j]; im[j] = re[j] * ci[j] + im[j] * cr[j]; re[j] = nr; }
     }
     return x;
+}
+
+static std::vector<int> parse_devices(const std::string& spec, int fallback) {   // "0-7", "0,2,5", "" -> {fallback}
+    std::vector<int> out;
+    if (trim(spec).empty()) { out.push_back(fallback); return out; }
+    size_t pos = 0;
+    while (pos <= spec.size()) {
+        size_t c = spec.find(',', pos);
+        std::string part = trim(spec.substr(pos, c == std::string::npos ? std::string::npos : c - pos));
+        if (!part.empty()) {
+            size_t dash = part.find('-');
+            int lo = atoi(part.c_str()), hi = dash == std::string::npos ? lo : atoi(part.c_str() + dash + 1);
+            if (hi < lo) throw std::runtime_error("bad --devices range: " + part);
+            for (int d = lo; d <= hi; d++) out.push_back(d);
+        }
+        if (c == std::string::npos) break;
+        pos = c + 1;
+    }
+    if (out.empty()) throw std::runtime_error("--devices names no device");
+    return out;
 }
 
 struct Timing { double preprocess_s = 0, model_only_s = 0, decode_s = 0, end_to_end_s = 0; };
@@ -249,13 +296,26 @@ int main(int argc, char** argv) {
         GenCfg gen = load_generation_cfg(a.onnx_dir + "/generation_config.json");
         if (!synthetic_model && !is_dir(a.onnx_dir)) throw std::runtime_error("onnx_dir does not exist or is not a directory: " + a.onnx_dir);
 
-        wh_model* model = nullptr;
         const int prec = a.precision == "f32" ? WH_PREC_F32 : a.precision == "fp8" ? WH_PREC_FP8 : WH_PREC_BF16;
-        if (int rc = wh_model_load(a.onnx_dir.c_str(), a.device, prec, &model))
-            throw std::runtime_error("Failed to load " + a.onnx_dir + ": libwhisper_hip error " + std::to_string(rc) + ": " + wh_last_error(nullptr));
-        wh_ctx* ctx = nullptr;
-        if (int rc = wh_ctx_create(model, a.max_batch, &ctx))
-            throw std::runtime_error(std::string("wh_ctx_create: ") + std::to_string(rc) + ": " + wh_last_error(nullptr));
+        // One model per device (the reference shares its three `&Session`s across the rayon pool, src/main.rs:890-919),
+        // `--streams-per-gpu` contexts per model, one host thread per context; files are independent units
+        // (src/main.rs:1164 loops over them serially) and are dealt to whichever context is free.
+        const std::vector<int> devices = parse_devices(a.devices, a.device);
+        std::vector<wh_model*> models;
+        std::vector<wh_ctx*> ctxs;
+        for (int dev : devices) {
+            wh_model* m = nullptr;
+            if (int rc = wh_model_load(a.onnx_dir.c_str(), dev, prec, &m))
+                throw std::runtime_error("Failed to load " + a.onnx_dir + " on device " + std::to_string(dev) + ": libwhisper_hip error " +
+                                         std::to_string(rc) + ": " + wh_last_error(nullptr));
+            models.push_back(m);
+            for (int st = 0; st < a.streams_per_gpu; st++) {
+                wh_ctx* c = nullptr;
+                if (int rc = wh_ctx_create(m, a.max_batch, &c))
+                    throw std::runtime_error(std::string("wh_ctx_create: ") + std::to_string(rc) + ": " + wh_last_error(nullptr));
+                ctxs.push_back(c);
+            }
+        }
 
         std::vector<std::string> files;
         if (a.synthetic_clips) {
@@ -283,27 +343,200 @@ int main(int argc, char** argv) {
         if (a.warmup > 0) {  // :1131-1152
             std::vector<float> a0; double d0;
             load(0, a0, d0);
-            for (size_t i = 0; i < a.warmup; i++) { Timing t; transcribe(ctx, a0, a, &tok, gen, t); }
+            for (wh_ctx* c : ctxs)
+                for (size_t i = 0; i < a.warmup; i++) { Timing t; transcribe(c, a0, a, &tok, gen, t); }
         }
+
+        // ---- the file loop (:1164-1213) as a pipeline: loader threads -> bounded queue -> one worker per context ----
+        struct Item {
+            size_t idx; std::vector<float> audio; double dur = 0, load_s = 0;
+            float* pin = nullptr; size_t n_pin = 0;                       // samples in a pool buffer instead of `audio`
+            size_t n() const { return pin ? n_pin : audio.size(); }
+            const float* data() const { return pin ? pin : audio.data(); }
+        };
+        struct PinnedPool {   // page-locked 30 s buffers, allocated once
+            std::vector<float*> free_list; size_t total = 0;
+            std::mutex m; std::condition_variable cv;
+            bool empty_pool() const { return total == 0; }
+            void init(size_t n) {
+                for (size_t i = 0; i < n; i++) {
+                    float* p = nullptr;
+                    if (hipHostMalloc((void**)&p, (size_t)WH_CLIP_SAMPLES * sizeof(float), hipHostMallocDefault) != hipSuccess) break;
+                    free_list.push_back(p);
+                }
+                total = free_list.size();
+            }
+            float* acquire() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return !free_list.empty(); }); float* p = free_list.back(); free_list.pop_back(); return p; }
+            void release(float* p) { { std::lock_guard<std::mutex> lk(m); free_list.push_back(p); } cv.notify_one(); }
+            ~PinnedPool() { for (float* p : free_list) (void)hipHostFree(p); }
+        } pool;
+        struct Result { std::string text; double dur = 0, load_s = 0; Timing t; bool ok = false; };
+        const size_t nfiles = files.size();
+        std::vector<Result> results(nfiles);
+        std::mutex mu;
+        std::condition_variable cv_items, cv_space;
+        std::deque<Item> ready;                   // loaded files, in index order
+        std::map<size_t, Item> parked;            // loaded out of order, waiting for their turn
+        size_t next_ready = 0;                    // index the queue is waiting for
+        size_t handed = 0;                        // files handed to workers so far (under mu)
+        std::atomic<size_t> next_load{0};
+        std::string first_error;
+        const size_t cap = (size_t)a.max_batch * ctxs.size() * 2 + 4;
+        const unsigned hc = std::thread::hardware_concurrency();
+        const int n_loaders = a.load_threads > 0 ? a.load_threads : (int)std::min<unsigned>(8, std::max<unsigned>(1, hc / 2));
+        pool.init(cap + (size_t)a.max_batch * ctxs.size() + (size_t)n_loaders);   // look-ahead + batches in flight + one per loader
+        auto loader = [&]() {
+            for (;;) {
+                const size_t i = next_load.fetch_add(1);
+                if (i >= nfiles) return;
+                Item it;
+                it.idx = i;
+                try {
+                    const double tl0 = now_s();
+                    load(i, it.audio, it.dur);
+                    it.load_s = now_s() - tl0;
+                    // one-window files move into a page-locked buffer of the pool, so the library's host-to-device copy is one
+                    // DMA at link speed (a pageable source goes through the runtime's staging buffers: 123 MB per 64-clip batch
+                    // cost 5 ms of a 70 ms batch); the pool is sized to the look-ahead, a loader waits for a free buffer
+                    if (it.audio.size() <= (size_t)WH_CLIP_SAMPLES && !pool.empty_pool()) {
+                        it.pin = pool.acquire();
+                        if (it.pin) {
+                            memcpy(it.pin, it.audio.data(), it.audio.size() * sizeof(float));
+                            it.n_pin = it.audio.size();
+                            std::vector<float>().swap(it.audio);
+                        }
+                    }
+                } catch (const std::exception& e) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (first_error.empty()) first_error = e.what();
+                    cv_items.notify_all();
+                    return;
+                }
+                std::unique_lock<std::mutex> lk(mu);
+                cv_space.wait(lk, [&] { return !first_error.empty() || i < handed + cap; });   // bounded look-ahead of the consumers
+                if (!first_error.empty()) return;
+                parked.emplace(i, std::move(it));
+                while (!parked.empty() && parked.begin()->first == next_ready) {
+                    ready.push_back(std::move(parked.begin()->second));
+                    parked.erase(parked.begin());
+                    next_ready++;
+                }
+                cv_items.notify_all();
+            }
+        };
+        WhisperSpecial sp = special_tokens(a.language, a.task, &tok);
+        std::vector<int64_t> prompt = {sp.sot, sp.lang, sp.task};
+        if (!a.timestamps) prompt.push_back(sp.no_timestamps);
+        std::vector<double> busy_s(ctxs.size(), 0.0);
+        auto worker = [&](size_t wi) {
+            wh_ctx* ctx = ctxs[wi];
+            const size_t stride = prompt.size() + a.max_new_tokens;
+            std::vector<int64_t> toks((size_t)a.max_batch * stride);
+            std::vector<size_t> ntok(a.max_batch);
+            for (;;) {
+                std::vector<Item> batch;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    // wait for a full batch, the end of the input, or a multi-window file at the front (it goes alone)
+                    cv_items.wait(lk, [&] {
+                        return !first_error.empty() || handed == nfiles || (int)ready.size() >= a.max_batch || handed + ready.size() == nfiles ||
+                               (!ready.empty() && ready.front().n() > (size_t)WH_CLIP_SAMPLES);
+                    });
+                    if (!first_error.empty() || ready.empty()) {
+                        if (!first_error.empty() || handed == nfiles) return;
+                        continue;
+                    }
+                    // a file longer than one window goes alone through the long-form entry (which batches its windows);
+                    // single-window files are batched together, at most max_batch, only what is already loaded
+                    if (ready.front().n() > (size_t)WH_CLIP_SAMPLES) {
+                        batch.push_back(std::move(ready.front()));
+                        ready.pop_front();
+                    } else {
+                        while (!ready.empty() && (int)batch.size() < a.max_batch && ready.front().n() <= (size_t)WH_CLIP_SAMPLES) {
+                            batch.push_back(std::move(ready.front()));
+                            ready.pop_front();
+                        }
+                    }
+                    handed += batch.size();
+                    cv_space.notify_all();
+                    if (handed == nfiles) cv_items.notify_all();
+                }
+                try {
+                    const double tb0 = now_s();
+                    if (batch.size() == 1 && batch[0].n() > (size_t)WH_CLIP_SAMPLES) {
+                        Result& r = results[batch[0].idx];
+                        r.text = transcribe(ctx, batch[0].audio, a, &tok, gen, r.t);
+                        r.dur = batch[0].dur; r.load_s = batch[0].load_s; r.ok = true;
+                    } else {
+                        // the per-window body of transcribe_longform_chunked (:870-915) for a batch of one-window files
+                        wh_decode_params p{};
+                        p.prompt = prompt.data(); p.n_prompt = prompt.size(); p.max_new_tokens = a.max_new_tokens; p.eot = sp.eot;
+                        p.suppress = gen.suppress.data(); p.n_suppress = gen.suppress.size();
+                        p.begin_suppress = gen.begin_suppress.data(); p.n_begin_suppress = gen.begin_suppress.size();
+                        std::vector<wh_clip> clips(batch.size());
+                        for (size_t k = 0; k < batch.size(); k++) { clips[k].pcm = batch[k].data(); clips[k].n_samples = batch[k].n(); }
+                        const double t0 = now_s();
+                        int rc = wh_transcribe_batch(ctx, clips.data(), clips.size(), &p, toks.data(), ntok.data());
+                        if (rc) throw std::runtime_error(std::string("libwhisper_hip error ") + std::to_string(rc) + ": " + wh_last_error(ctx));
+                        const double batch_s = now_s() - t0;
+                        wh_timing wt{};
+                        wh_get_timings(ctx, &wt);
+                        for (size_t k = 0; k < batch.size(); k++) {   // :926-943
+                            Result& r = results[batch[k].idx];
+                            const double td0 = now_s();
+                            std::vector<int64_t> g;
+                            if (ntok[k] > prompt.size()) g.assign(toks.begin() + k * stride + prompt.size(), toks.begin() + k * stride + ntok[k]);
+                            if (!g.empty() && g.back() == sp.eot) g.pop_back();
+                            std::string text = decode_tokens(g, &tok);
+                            if (text.empty()) text = "[EMPTY]";
+                            std::vector<std::string> texts;
+                            if (text != "[EMPTY]") texts.push_back(text);
+                            r.text = stitch_texts(texts);
+                            r.t.preprocess_s = wt.preprocess_s;
+                            r.t.model_only_s = wt.encode_s + wt.decode_s;
+                            r.t.decode_s = now_s() - td0;
+                            r.t.end_to_end_s = batch_s + r.t.decode_s;   // every clip of a batch completes with its batch
+                            r.dur = batch[k].dur; r.load_s = batch[k].load_s; r.ok = true;
+                        }
+                    }
+                    busy_s[wi] += now_s() - tb0;
+                    for (Item& it : batch)
+                        if (it.pin) pool.release(it.pin);
+                } catch (const std::exception& e) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (first_error.empty()) first_error = e.what();
+                    cv_items.notify_all();
+                    cv_space.notify_all();
+                    return;
+                }
+            }
+        };
+        const double loop0 = now_s();
+        std::vector<std::thread> threads;
+        for (int i = 0; i < n_loaders; i++) threads.emplace_back(loader);
+        for (size_t wi = 0; wi < ctxs.size(); wi++) threads.emplace_back(worker, wi);
+        for (auto& t : threads) t.join();
+        const double loop_s = now_s() - loop0;
+        if (!first_error.empty()) throw std::runtime_error(first_error);
+
         std::vector<RowOut> rows;
         std::vector<double> e2e, loadl, pre, model_only, dec, rtfl;
         const std::string txt_dir = parent_dir(a.out_csv);
-        for (size_t i = 0; i < files.size(); i++) {  // :1164-1213
-            const double tl0 = now_s();
-            std::vector<float> audio; double dur;
-            load(i, audio, dur);
-            const double load_s = now_s() - tl0;
-            Timing t;
-            std::string text = transcribe(ctx, audio, a, &tok, gen, t);
-            const double end_to_end = load_s + t.end_to_end_s;
-            rows.push_back(make_row(files[i], dur, end_to_end, text));
-            loadl.push_back(load_s); pre.push_back(t.preprocess_s); model_only.push_back(t.model_only_s);
-            dec.push_back(t.decode_s); e2e.push_back(end_to_end); rtfl.push_back(end_to_end / std::max(dur, 1e-9));
+        double audio_total = 0;
+        for (size_t i = 0; i < nfiles; i++) {
+            const Result& r = results[i];
+            if (!r.ok) throw std::runtime_error("file " + files[i] + " was not processed");
+            const double end_to_end = r.load_s + r.t.end_to_end_s;   // :1190
+            rows.push_back(make_row(files[i], r.dur, end_to_end, r.text));
+            loadl.push_back(r.load_s); pre.push_back(r.t.preprocess_s); model_only.push_back(r.t.model_only_s);
+            dec.push_back(r.t.decode_s); e2e.push_back(end_to_end); rtfl.push_back(end_to_end / std::max(r.dur, 1e-9));
+            audio_total += r.dur;
             if (a.write_txt) {
                 std::string base = files[i].substr(0, files[i].rfind('.'));
-                write_file((txt_dir.empty() ? "." : txt_dir) + "/" + base + ".transcript.txt", trim(text) + "\n");
+                write_file((txt_dir.empty() ? "." : txt_dir) + "/" + base + ".transcript.txt", trim(r.text) + "\n");
             }
         }
+        const double busy_max = *std::max_element(busy_s.begin(), busy_s.end());
         write_file(a.out_csv, csv_text(rows));
         write_file(a.out_json, per_file_json(rows));
         JVal summary = JVal::obj();  // :1235-1257 (+ additive keys gpu, rtfx_end_to_end)
@@ -319,8 +552,14 @@ int main(int argc, char** argv) {
             .set("notes", JVal::obj().set("longform", JVal::str("Rust approximation: chunked 30s windows with overlap; greedy decode via decoder_with_past"))
                               .set("token_decode", JVal::str(tok.loaded ? "Tokenizer decode (skip_special_tokens=true)" : "Prints token IDs unless you provide tokenizer.json.")))
             .set("rtfx_end_to_end", stat_json(stat_block(rtfx)))
-            .set("gpu", JVal::obj().set("backend", JVal::str("libwhisper_hip (gfx950)")).set("device", JVal::integer(a.device))
-                            .set("precision", JVal::str(a.precision)).set("max_batch", JVal::integer(a.max_batch)));
+            .set("gpu", JVal::obj().set("backend", JVal::str("libwhisper_hip (gfx950)")).set("device", JVal::integer(devices[0]))
+                            .set("devices", JVal::integer((long long)devices.size())).set("streams_per_gpu", JVal::integer(a.streams_per_gpu))
+                            .set("precision", JVal::str(a.precision)).set("max_batch", JVal::integer(a.max_batch))
+                            .set("load_threads", JVal::integer(n_loaders)).set("audio_s", JVal::num(audio_total))
+                            // whole-job throughput: audio seconds per wall second of the file loop (loading overlapped), and per
+                            // second the busiest context spent inside the library (what bench.py measures with PCM resident)
+                            .set("wall_s", JVal::num(loop_s)).set("throughput_rtfx", JVal::num(audio_total / std::max(loop_s, 1e-12)))
+                            .set("gpu_busy_s", JVal::num(busy_max)).set("gpu_throughput_rtfx", JVal::num(audio_total / std::max(busy_max, 1e-12))));
         write_file(a.out_summary_json, summary.pretty());
         printf("DONE\n");  // :1261-1268
         printf("Config used:\n%s\n", cfg.json(false).pretty().c_str());
@@ -329,8 +568,8 @@ int main(int argc, char** argv) {
         printf("Summary JSON: %s\n", a.out_summary_json.c_str());
         double p95 = stat_block(e2e).p95;
         if (std::isfinite(p95)) printf("End-to-end p95(s): %.6f\n", p95);
-        wh_ctx_free(ctx);
-        wh_model_free(model);
+        for (wh_ctx* c : ctxs) wh_ctx_free(c);
+        for (wh_model* m : models) wh_model_free(m);
     } catch (const std::exception& e) {
         fprintf(stderr, "Error: %s\n", e.what());
         return 1;
