@@ -77,6 +77,7 @@ def lib() -> C.CDLL:
         L.orc_e4m3_quantize.argtypes = [f32p, C.c_size_t, u8p]
         L.orc_e4m3_dequantize.argtypes = [u8p, C.c_size_t, f32p]
         L.orc_set_kv_fp8.argtypes = [C.c_int]
+        L.orc_set_act_mx.argtypes = [C.c_int]
         L.orc_num_threads.restype = C.c_int
         L.orc_set_threads.argtypes = [C.c_int]
         L.orc_set_threads(int(os.environ["OMP_NUM_THREADS"]))
@@ -126,12 +127,23 @@ def window_mel(mel_full: np.ndarray, frame_start: int, win_frames: int = 3000) -
     return out
 
 
-def encoder(dims, wflat: np.ndarray, mel: np.ndarray) -> np.ndarray:
+def mx_applies(dims) -> bool:
+    """The build's fp8 mode uses MX activations (fp8 MFMA) when every contraction length is 256 / 512 / 1024 / 2048."""
+    ok = (256, 512, 1024, 2048)
+    return dims.d_model in ok and dims.ffn in ok
+
+
+def encoder(dims, wflat: np.ndarray, mel: np.ndarray, act_mx: bool = False) -> np.ndarray:
+    """act_mx: LayerNorm and GELU outputs pass through MX (block-32 power-of-two scaled e4m3) — the build's fp8 mode."""
     mel = np.ascontiguousarray(mel, np.float32)
     assert mel.shape == (dims.n_mels, 2 * dims.n_audio_ctx), mel.shape
     assert wflat.dtype == np.float32 and wflat.size == int(lib().orc_n_params(C.byref(dims_struct(dims))))
     out = np.empty((dims.n_audio_ctx, dims.d_model), np.float32)
-    rc = lib().orc_encoder(C.byref(dims_struct(dims)), _f32(wflat), _f32(mel), _f32(out))
+    lib().orc_set_act_mx(1 if act_mx else 0)
+    try:
+        rc = lib().orc_encoder(C.byref(dims_struct(dims)), _f32(wflat), _f32(mel), _f32(out))
+    finally:
+        lib().orc_set_act_mx(0)
     if rc:
         raise RuntimeError(f"orc_encoder rc={rc}")
     return out
@@ -151,9 +163,10 @@ def argmax_last_row(logits: np.ndarray, suppress: Sequence[int] = ()) -> int:
 
 def decode_greedy(dims, wflat: np.ndarray, enc: np.ndarray, prompt: Sequence[int], max_new: int, eot: int,
                   suppress: Sequence[int] = (), begin_suppress: Sequence[int] = (),
-                  forced: Optional[Sequence[int]] = None, want_logits: bool = False, kv_fp8: bool = False
-                  ) -> Tuple[np.ndarray, Optional[np.ndarray]]:
-    """kv_fp8: cross-attention K/V pass through e4m3 with one scale per (layer, K|V, head) — the build's fp8 mode."""
+                  forced: Optional[Sequence[int]] = None, want_logits: bool = False, kv_fp8: bool = False,
+                  act_mx: bool = False) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+    """kv_fp8: cross-attention K/V pass through e4m3 with one scale per (layer, K|V, head) — the build's fp8 mode;
+    act_mx: the encoder states enter the cross K/V projections in MX form (see encoder)."""
     enc = np.ascontiguousarray(enc, np.float32)
     pr = np.asarray(list(prompt), np.int64)
     sup = np.asarray(list(suppress), np.int64)
@@ -163,6 +176,7 @@ def decode_greedy(dims, wflat: np.ndarray, enc: np.ndarray, prompt: Sequence[int
     n_out = C.c_size_t(0)
     logits = np.zeros((max_new, dims.vocab), np.float32) if want_logits else None
     lib().orc_set_kv_fp8(1 if kv_fp8 else 0)
+    lib().orc_set_act_mx(1 if act_mx else 0)
     try:
         rc = lib().orc_decode_greedy(C.byref(dims_struct(dims)), _f32(wflat), _f32(enc), _i64(pr), pr.size, max_new,
                                      eot, _i64(sup), sup.size, _i64(bsup), bsup.size,
@@ -170,6 +184,7 @@ def decode_greedy(dims, wflat: np.ndarray, enc: np.ndarray, prompt: Sequence[int
                                      _f32(logits) if want_logits else None)
     finally:
         lib().orc_set_kv_fp8(0)
+        lib().orc_set_act_mx(0)
     if rc:
         raise RuntimeError(f"orc_decode_greedy rc={rc}")
     n = int(n_out.value)

@@ -386,6 +386,9 @@ static void softmax_row(float* s, size_t n) {
  *            WhisperEncoderLayer.forward (:385-399), WhisperAttention.forward (:279-357)
  * mel: [n_mels][2*n_audio_ctx] row-major;  out: [n_audio_ctx][d_model]
  * ---------------------------------------------------------------------------------------- */
+static int g_act_mx;                                         /* fp8 section below */
+static void fake_quant_mx(float* x, size_t rows, size_t K);
+
 int orc_encoder(const orc_dims* c, const float* w, const float* mel, float* out) {
     model_w m;
     int rc = map_weights(c, w, &m);
@@ -426,6 +429,7 @@ int orc_encoder(const orc_dims* c, const float* w, const float* mel, float* out)
     for (int li = 0; li < c->enc_layers; li++) {
         const enc_layer_w* lw = &m.enc[li];
         layer_norm(x, &lw->sa_ln, xn, T, d);
+        if (g_act_mx) fake_quant_mx(xn, T, d);
         gemm_nt(xn, d, lw->sa.qw, lw->sa.qb, q, d, T, d, d);
         for (size_t i = 0; i < T * d; i++) q[i] *= scaling; /* :309 scale q BEFORE QK^T */
         gemm_nt(xn, d, lw->sa.kw, NULL, k, d, T, d, d);
@@ -457,8 +461,10 @@ int orc_encoder(const orc_dims* c, const float* w, const float* mel, float* out)
         gemm_nt(ao, d, lw->sa.ow, lw->sa.ob, xn, d, T, d, d);
         for (size_t i = 0; i < T * d; i++) x[i] += xn[i];
         layer_norm(x, &lw->fin_ln, xn, T, d);
+        if (g_act_mx) fake_quant_mx(xn, T, d);
         gemm_nt(xn, d, lw->mlp.w1, lw->mlp.b1, hb, F, T, F, d);
         for (size_t i = 0; i < T * F; i++) hb[i] = gelu(hb[i]);
+        if (g_act_mx) fake_quant_mx(hb, T, F);
         gemm_nt(hb, F, lw->mlp.w2, lw->mlp.b2, xn, d, T, d, F);
         for (size_t i = 0; i < T * d; i++) x[i] += xn[i];
     }
@@ -614,6 +620,31 @@ void orc_e4m3_dequantize(const uint8_t* c, size_t n, float* out) { for (size_t i
  * block, values stored as e4m3 codes of value / scale — restated as quantise-dequantise in place. */
 static int g_kv_fp8 = 0;
 void orc_set_kv_fp8(int on) { g_kv_fp8 = on; }
+
+/* MX activations of the build's fp8-MFMA encoder (whisper-rust-ort_amd/csrc/wh_gemm8_mx.hip): every 32 consecutive
+ * elements of a row share a power-of-two scale 2^(eb-127), eb = max(0, E - 8 + (mantissa > 1.75)) from the block's largest
+ * magnitude (E = its biased f32 exponent), so that the maximum maps into (224, 448]; elements are stored as e4m3 codes of
+ * value * 2^(127-eb).  Restated as quantise-dequantise in place.  Applied where the HIP path quantises: the LayerNorm
+ * outputs that feed the q/k/v and fc1 projections, the GELU output that feeds fc2, and the encoder output as the operand
+ * of the cross-attention K/V projections.  Reference analogue: dynamic activation quantisation of MatMul/Gemm,
+ * quantize_onnx_int8.py:37-42. */
+static int g_act_mx = 0;
+void orc_set_act_mx(int on) { g_act_mx = on; }
+static void fake_quant_mx(float* x, size_t rows, size_t K) {
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < (long)rows; r++)
+        for (size_t b0 = 0; b0 + 32 <= K; b0 += 32) {
+            float* v = x + (size_t)r * K + b0;
+            float am = 0.0f;
+            for (int i = 0; i < 32; i++) am = fmaxf(am, fabsf(v[i]));
+            uint32_t ab;
+            memcpy(&ab, &am, 4);
+            int eb = (int)((ab >> 23) & 0xFF) - 8 + (int)((ab & 0x7FFFFF) > 0x600000);
+            if (eb < 0) eb = 0;
+            const float inv = ldexpf(1.0f, 127 - eb), sc = ldexpf(1.0f, eb - 127);
+            for (int i = 0; i < 32; i++) v[i] = e4m3_to_f32(e4m3_from_f32(v[i] * inv)) * sc;
+        }
+}
 static void fake_quant_heads(float* kv /* [T][d] */, size_t T, size_t d, size_t n_heads) {
     const size_t hd = d / n_heads;
     for (size_t h = 0; h < n_heads; h++) {
@@ -653,6 +684,13 @@ int orc_decode_greedy(const orc_dims* c, const float* w, const float* enc /* [T]
     st.sc = (float*)malloc(sizeof(float) * (size_t)c->n_heads * (T > TC ? T : TC));
     float* logits = (float*)malloc(sizeof(float) * V);
     /* cross K/V once per clip: present.{i}.encoder.{key,value} of step 0 (src/main.rs:786-787) */
+    float* enc_q = NULL;   /* MX form of the encoder states as the projections' operand */
+    if (g_act_mx) {
+        enc_q = (float*)malloc(sizeof(float) * T * d);
+        memcpy(enc_q, enc, sizeof(float) * T * d);
+        fake_quant_mx(enc_q, T, d);
+        enc = enc_q;
+    }
     for (size_t li = 0; li < Ld; li++) {
         gemm_nt(enc, d, st.m.dec[li].ca.kw, NULL, st.crossk + li * T * d, d, T, d, d);
         gemm_nt(enc, d, st.m.dec[li].ca.vw, st.m.dec[li].ca.vb, st.crossv + li * T * d, d, T, d, d);
@@ -693,7 +731,7 @@ int orc_decode_greedy(const orc_dims* c, const float* w, const float* enc /* [T]
         }
     }
     *n_out = n;
-    free(sup_first); free(logits);
+    free(sup_first); free(logits); free(enc_q);
     free(st.selfk); free(st.selfv); free(st.crossk); free(st.crossv);
     free(st.x); free(st.xn); free(st.q); free(st.ao); free(st.hb); free(st.sc);
     unmap_weights(&st.m);

@@ -2,6 +2,8 @@
 run on the SAME quantised model: weights through modelspec.fake_quant_state_dict (dequant(quant(W)), bit-identical
 to the library's own quantiser — tests/test_fp8_cpu.py), cross K/V through the oracle's kv_fp8 switch.  What is
 left between the two is bf16 activations vs f32, so the bounds are those of the bf16 mode."""
+import os
+
 import numpy as np
 import pytest
 
@@ -23,16 +25,19 @@ def small_prompt(dims):
     return ([50258, 50259, 50359, 50363], 50257) if dims.vocab > 50400 else ([3, 5, 7, 9], 2)
 
 
-@pytest.mark.parametrize("preset,seed,clip,n_new", [("nano", 7, 0, 24), ("micro", 11, 2, 16)])
+@pytest.mark.parametrize("preset,seed,clip,n_new", [("nano", 7, 0, 24), ("micro", 11, 2, 16), ("base", 1234, 0, 8)])
 def test_fp8_teacher_forced_vs_quantised_oracle(gpu, preset, seed, clip, n_new):
+    """The fp8 mode against the oracle run on the same quantised model: e4m3 weights (fake-quantised), e4m3 cross K/V, and —
+    where the geometry allows the fp8-MFMA encoder (micro, base) — MX activations at the same points the HIP path quantises."""
     dims = ms.PRESETS[preset]
+    mx = orc.mx_applies(dims)
     sd = ms.synth_state_dict(dims, seed)
     wq = ms.flatten_state_dict(dims, ms.fake_quant_state_dict(sd))
     pcm = ms.synth_clip(clip)
     prompt, eot = small_prompt(dims)
     mel = orc.window_mel(orc.log_mel(pcm, dims.n_mels), 0, 3000)
-    enc_o = orc.encoder(dims, wq, mel)
-    tok_o, log_o = orc.decode_greedy(dims, wq, enc_o, prompt, n_new, eot, suppress=[eot], want_logits=True, kv_fp8=True)
+    enc_o = orc.encoder(dims, wq, mel, act_mx=mx)
+    tok_o, log_o = orc.decode_greedy(dims, wq, enc_o, prompt, n_new, eot, suppress=[eot], want_logits=True, kv_fp8=True, act_mx=mx)
     gen = tok_o[len(prompt):].tolist()
 
     model = wb.Model(f"synthetic:{preset}:{seed}", 0, wb.WH_PREC_FP8)
@@ -40,7 +45,17 @@ def test_fp8_teacher_forced_vs_quantised_oracle(gpu, preset, seed, clip, n_new):
     ctx = wb.Context(model, 1)
     enc = ctx.run_encoder(ctx.whisper_log_mel(pcm))
     enc_err = np.abs(enc - enc_o).max()
-    assert enc_err < 0.08, enc_err
+    if mx:
+        # MX activations: a 3-bit-mantissa code flips wherever the bf16 parts of the HIP path (attention, out-projection,
+        # convolutions) move a value across a rounding boundary, so element-wise agreement with the f32 oracle is not the bar
+        # (the kernels themselves are checked exactly: test_mx_kernels_match_host_restatement).  The bar: closer to the MX
+        # oracle than the quantisation itself moves the states.
+        enc_plain = orc.encoder(dims, wq, mel)
+        d_mx, d_plain, q_shift = np.abs(enc - enc_o).mean(), np.abs(enc - enc_plain).mean(), np.abs(enc_o - enc_plain).mean()
+        print(f"{preset}: encoder mean |hip - oracle_mx| {d_mx:.4f}, |hip - oracle_plain| {d_plain:.4f}, |oracle_mx - oracle_plain| {q_shift:.4f}, max {enc_err:.3f}")
+        assert d_mx < q_shift and d_mx < d_plain and enc_err < 1.0
+    else:
+        assert enc_err < 0.08, enc_err
     tc, lc = ctx.greedy_decode_with_past(wb.DecodeParams(prompt, n_new, eot, [eot], forced=gen[:-1]), want_logits=True)
     assert len(lc) == len(log_o)
     errs = [np.abs(lc[i] - log_o[i]).max() for i in range(len(lc))]
@@ -53,7 +68,7 @@ def test_fp8_teacher_forced_vs_quantised_oracle(gpu, preset, seed, clip, n_new):
             agree += int(tc[len(prompt) + i] == gen[i])
     print(f"{preset}: fp8 vs quantised oracle: encoder err {enc_err:.4f}, max logit err {max(errs):.4f}, "
           f"mean {np.mean(errs):.4f}; decided {decided}/{len(lc)} agree {agree}")
-    assert max(errs) < 0.25
+    assert max(errs) < (1.5 if mx else 0.25)   # MX: the bound of test_fp8_base_256_vs_64_clip_context_logit_bound (quantisation noise of this synthetic model)
     assert agree == decided
 
     # the quantisation itself moves the logits by far more than the bf16 arithmetic does: the fp8 run must sit
@@ -119,3 +134,17 @@ def test_fp8_base_256_vs_64_clip_context_logit_bound(gpu, golden_dir):
     assert d_ctx.max() < 0.15
     # e4m3 weights + e4m3 cross K/V against the f32 golden vectors: reported (profiles/*fp8_accuracy*), loosely bounded here
     assert max(e256, e64, e3) < 1.5
+
+
+def test_mx_kernels_match_host_restatement(gpu):
+    """k_layernorm_mx and k_gemm8_mx (fp8 MFMA with block exponents) against a host restatement, at K = 256 / 512 / 2048
+    with a row tail: LayerNorm codes and exponents bit for bit, GEMM within the bf16 rounding of its output, the MX output
+    within one e4m3 step; and the operand / scale layout of v_mfma_scale_f32_16x16x128_f8f6f4 the kernel relies on."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for tool in ("mx_mfma_check", "mx_gemm_check"):
+        exe = os.path.join(root, "tools", tool)
+        assert os.path.exists(exe), f"{exe} missing: __graft_entry__.build() compiles it"
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+        print(r.stdout)
+        assert r.returncode == 0, r.stdout + r.stderr

@@ -131,13 +131,21 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
     const long rows = (long)nb * S;
     for (int l = 0; l < D.enc_layers; l++) {
         const EncLayerDev& L = m->enc[l];
-        { Prof p(c, WH_KG_ENC_GEMM); wh_launch_layernorm(s, prec, c->x, L.ln1_w, L.ln1_b, c->xn, rows, (int)d); }
+        // WH_PREC_FP8 with MX activations: LayerNorm writes e4m3 codes + block exponents and the three GEMMs it feeds run
+        // on the fp8 matrix cores (e4m3 weights x MX activations); otherwise bf16 operands (fp8 weights as code values)
+        const bool mx = c->mx_ok && rows >= 256;
+        {
+            Prof p(c, WH_KG_ENC_GEMM);
+            if (mx) wh_launch_layernorm_mx(s, c->x, L.ln1_w, L.ln1_b, c->xn8, c->xn8_sc, rows, (int)d);
+            else wh_launch_layernorm(s, prec, c->x, L.ln1_w, L.ln1_b, c->xn, rows, (int)d);
+        }
         {   // Q|K projection (q pre-scaled, k has no bias)
             Prof p(c, WH_KG_ENC_GEMM);
             GemmArgs g;
             g.A = c->xn; g.lda = d; g.W = L.qk_w; g.ldw = d; g.C = c->qk; g.ldc = 2 * d;
             g.bias = L.qk_b; g.bias_mode = 1; g.wscale = L.qk_sc; g.M = (int)rows; g.N = (int)(2 * d); g.K = (int)d;
-            wh_launch_gemm(s, prec, false, g);
+            if (mx) { g.A = c->xn8; g.a_sc = c->xn8_sc; g.W = L.qk_w8; wh_launch_gemm8_mx(s, 0, g); }
+            else wh_launch_gemm(s, prec, false, g);
         }
         {   // V^T[e][key] = W_v x^T + b_v: per-clip product with the weight as the row operand
             Prof p(c, WH_KG_ENC_GEMM);
@@ -146,7 +154,9 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
             g.W = c->xn; g.ldw = d; g.w_zs = S * d;
             g.C = c->vT; g.ldc = c->ldv; g.c_zs = d * c->ldv;
             g.bias = L.v_b; g.bias_mode = 2; g.wscale = L.v_sc; g.M = (int)d; g.N = (int)S; g.K = (int)d; g.batch = nb;
-            wh_launch_gemm(s, prec, false, g);
+            if (mx && d >= 256) { g.A = L.v_w8; g.W = c->xn8; g.w_sc8 = c->xn8_sc; g.w_sc_zs = S * d / 32; wh_launch_gemm8_mx(s, 0, g); }
+            else if (mx) return fail(c, WH_ERR_UNSUPPORTED, "MX activations need d_model >= 256");
+            else wh_launch_gemm(s, prec, false, g);
         }
         {
             Prof p(c, WH_KG_ENC_ATTN);
@@ -159,25 +169,33 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
             g.bias = L.o_b; g.bias_mode = 1; g.wscale = L.o_sc; g.R = c->x; g.ldr = d; g.M = (int)rows; g.N = (int)d; g.K = (int)d;
             wh_launch_gemm(s, prec, true, g);
         }
-        { Prof p(c, WH_KG_ENC_GEMM); wh_launch_layernorm(s, prec, c->x, L.ln2_w, L.ln2_b, c->xn, rows, (int)d); }
         {
+            Prof p(c, WH_KG_ENC_GEMM);
+            if (mx) wh_launch_layernorm_mx(s, c->x, L.ln2_w, L.ln2_b, c->xn8, c->xn8_sc, rows, (int)d);
+            else wh_launch_layernorm(s, prec, c->x, L.ln2_w, L.ln2_b, c->xn, rows, (int)d);
+        }
+        {   // fc1 + GELU (MX: the output leaves as e4m3 codes + block exponents, fc2's operand)
             Prof p(c, WH_KG_ENC_GEMM);
             GemmArgs g;
             g.A = c->xn; g.lda = d; g.W = L.fc1_w; g.ldw = d; g.C = c->hbuf; g.ldc = F;
             g.bias = L.fc1_b; g.bias_mode = 1; g.wscale = L.fc1_sc; g.act = 1; g.M = (int)rows; g.N = (int)F; g.K = (int)d;
-            wh_launch_gemm(s, prec, false, g);
+            if (mx) { g.A = c->xn8; g.a_sc = c->xn8_sc; g.W = L.fc1_w8; g.C = c->h8; g.c_sc = c->h8_sc; wh_launch_gemm8_mx(s, 2, g); }
+            else wh_launch_gemm(s, prec, false, g);
         }
         {
             Prof p(c, WH_KG_ENC_GEMM);
             GemmArgs g;
             g.A = c->hbuf; g.lda = F; g.W = L.fc2_w; g.ldw = F; g.C = c->x; g.ldc = d;
             g.bias = L.fc2_b; g.bias_mode = 1; g.wscale = L.fc2_sc; g.R = c->x; g.ldr = d; g.M = (int)rows; g.N = (int)d; g.K = (int)F;
-            wh_launch_gemm(s, prec, true, g);
+            if (mx) { g.A = c->h8; g.a_sc = c->h8_sc; g.W = L.fc2_w8; wh_launch_gemm8_mx(s, 1, g); }
+            else wh_launch_gemm(s, prec, true, g);
         }
     }
     {
         Prof p(c, WH_KG_ENC_GEMM);
         wh_launch_layernorm(s, prec, c->x, m->enc_ln_w, m->enc_ln_b, c->enc_out, rows, (int)d);
+        if (c->mx_ok && rows >= 256)   // the cross K/V projection's operand in MX form
+            wh_launch_layernorm_mx(s, c->x, m->enc_ln_w, m->enc_ln_b, c->xn8, c->xn8_sc, rows, (int)d);
         if (want_f32) {
             if (prec == WH_PREC_F32) hipMemcpyAsync(c->enc_out_f32, c->enc_out, rows * d * 4, hipMemcpyDeviceToDevice, s);
             else wh_launch_layernorm(s, WH_PREC_F32, c->x, m->enc_ln_w, m->enc_ln_b, c->enc_out_f32, rows, (int)d);
@@ -273,7 +291,8 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
         g.C = c->cross_kv; g.ldc = d; g.n_per = (int)d; g.c_ns = kv_stride;
         g.bias = m->cross_kv_b; g.bias_mode = 1; g.wscale = m->cross_kv_sc;
         g.M = nb * (int)S; g.N = (int)(D.dec_layers * 2 * d); g.K = (int)d;
-        wh_launch_gemm(s, prec, false, g);
+        if (c->mx_ok && g.M >= 256) { g.A = c->xn8; g.a_sc = c->xn8_sc; g.W = m->cross_kv_w8; wh_launch_gemm8_mx(s, 0, g); }   // xn8 = MX(final LN), run_encoder
+        else wh_launch_gemm(s, prec, false, g);
         if (f8) {  // bf16 projection → e4m3 codes, one scale per (layer, K|V, clip, head)
             const long planes = (long)D.dec_layers * 2 * nb;
             CTX_HIP(c, hipMemsetAsync(c->kv_amax, 0, planes * D.n_heads * 4, s));
@@ -638,6 +657,11 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
     const size_t o_ckv = cv.take(Ld * 2 * B * S * d * esz);
     const bool f8 = m->prec == WH_PREC_FP8;
     const size_t o_ckv8 = f8 ? cv.take(Ld * 2 * B * S * d) : 0, o_kvam = f8 ? cv.take(Ld * 2 * B * H * 4) : 0;
+    // fp8-MFMA encoder (wh_gemm8_mx.hip): MX activations when every contraction length is one the kernel takes
+    auto mx_k = [](size_t k) { return k == 256 || k == 512 || k == 1024 || k == 2048; };
+    c->mx_ok = f8 && mx_k(d) && mx_k(F) && (d % 256) == 0 && getenv("WH_NO_MX") == nullptr;
+    const size_t o_xn8 = c->mx_ok ? cv.take(B * S * d) : 0, o_xn8s = c->mx_ok ? cv.take(B * S * d / 32) : 0;
+    const size_t o_h8 = c->mx_ok ? cv.take(B * S * F) : 0, o_h8s = c->mx_ok ? cv.take(B * S * F / 32) : 0;
     const size_t o_sk = cv.take(Ld * B * H * TC * WH_HEAD_DIM * esz), o_sv = cv.take(Ld * B * H * TC * WH_HEAD_DIM * esz);
     const size_t MP = align_up(B, 16);  // slab-layout activations: [K/32][MP][32]
     const size_t o_dx = cv.take(B * d * 4), o_dxn = cv.take(MP * d * esz), o_dqkv = cv.take(B * 3 * d * esz);
@@ -661,6 +685,10 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
     c->vT = w + o_vT; c->att = w + o_att; c->hbuf = w + o_h; c->enc_out = w + o_enc; c->enc_out_f32 = (float*)(w + o_encf);
     c->cross_kv = w + o_ckv; c->self_k = w + o_sk; c->self_v = w + o_sv;
     if (f8) { c->cross_kv8 = w + o_ckv8; c->kv_amax = (float*)(w + o_kvam); }
+    if (c->mx_ok) {
+        c->xn8 = (unsigned char*)(w + o_xn8); c->xn8_sc = (unsigned char*)(w + o_xn8s);
+        c->h8 = (unsigned char*)(w + o_h8); c->h8_sc = (unsigned char*)(w + o_h8s);
+    }
     c->dx = (float*)(w + o_dx); c->dxn = w + o_dxn; c->dxs = w + o_dxs; c->lnpart = (float*)(w + o_lnp); c->dqkv = w + o_dqkv; c->datt = w + o_datt; c->dq = w + o_dq; c->dh = w + o_dh;
     c->cpart = (float*)(w + o_cpart); c->cml = (float*)(w + o_cml); c->part_val = (float*)(w + o_pv); c->part_idx = (int*)(w + o_pi);
     c->feed = (int*)(w + o_feed); c->out_tokens = (int*)(w + o_out); c->n_out = (int*)(w + o_nout); c->done = (int*)(w + o_done);

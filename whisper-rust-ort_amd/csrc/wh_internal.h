@@ -15,6 +15,8 @@ struct EncLayerDev {
     float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
     // WH_PREC_FP8: the matrices above hold the e4m3 code VALUES (exact in bf16); these are the per-output-channel scales
     float *qk_sc = nullptr, *v_sc = nullptr, *o_sc = nullptr, *fc1_sc = nullptr, *fc2_sc = nullptr;
+    // ... and these the raw e4m3 codes [N][K] (one byte each) for the fp8-MFMA GEMMs (wh_gemm8_mx.hip)
+    void *qk_w8 = nullptr, *v_w8 = nullptr, *fc1_w8 = nullptr, *fc2_w8 = nullptr;
 };
 struct DecLayerDev {
     void *qkv_w, *o_w, *cq_w, *co_w, *fc1_w, *fc2_w;
@@ -44,6 +46,7 @@ struct wh_model {
     float *conv1_b = nullptr, *conv2_b = nullptr, *enc_pos = nullptr, *dec_pos = nullptr, *cross_kv_b = nullptr;
     float *enc_ln_w = nullptr, *enc_ln_b = nullptr, *dec_ln_w = nullptr, *dec_ln_b = nullptr;
     float* cross_kv_sc = nullptr;  // WH_PREC_FP8: scales of the cross K/V projection rows [Ld][2][d]
+    void* cross_kv_w8 = nullptr;   // WH_PREC_FP8: the same rows as raw e4m3 codes
     void* lm_w = nullptr;  // tied embedding ⊙ final-LN γ (LM head operand); WH_PREC_FP8: the embedding itself (γ on the activation side)
     float *lm_s = nullptr, *lm_c = nullptr;
     std::vector<EncLayerDev> enc;
@@ -99,6 +102,10 @@ struct wh_ctx {
     void* att = nullptr;        // [B][S][d]
     void* hbuf = nullptr;       // [B][S][ffn]
     void* enc_out = nullptr;    // [B][S][d] compute dtype (cross-KV GEMM operand)
+    // WH_PREC_FP8, MX activations (e4m3 codes + E8M0 block exponents [row][4][K/128]) when the geometry allows (mx_ok)
+    bool mx_ok = false;
+    unsigned char *xn8 = nullptr, *xn8_sc = nullptr;   // LayerNorm outputs [B*S][d]
+    unsigned char *h8 = nullptr, *h8_sc = nullptr;     // GELU(fc1) [B*S][ffn]
     float* enc_out_f32 = nullptr;  // [B][S][d] f32 (API output)
     int ldv = 0;
     void* cross_kv = nullptr;   // [Ld][2][B][S][d]

@@ -22,6 +22,12 @@ struct GemmArgs {
     int n_per = 1 << 30;       // column n stored at (n / n_per) * c_ns + (n % n_per)
     long c_ns = 0;
     int batch = 1;             // gridDim.z, pointer strides *_zs
+    // wh_gemm8_mx.hip (WH_PREC_FP8): A and W hold e4m3 codes (one byte per element; lda, ldw, a_bs, *_zs in elements = bytes)
+    // with E8M0 block exponents per (row, 32 consecutive k), layout [row][4][K/128]; null = no block exponents (weights)
+    const unsigned char* a_sc = nullptr;
+    const unsigned char* w_sc8 = nullptr;
+    long a_sc_zs = 0, w_sc_zs = 0;
+    unsigned char* c_sc = nullptr;   // MX output: block exponents of C (C itself receives the codes), layout [row][4][N/128]
 };
 
 struct SkinnyArgs {
@@ -106,6 +112,11 @@ void wh_launch_gemm(hipStream_t s, int prec, bool out_f32, const GemmArgs& g);
 // wh_gemm8.hip: the 8-wave LDS-DMA kernel (bf16 operands) for problems with at least one full 256 x 128 tile
 bool wh_gemm8_applicable(const GemmArgs& g);
 void wh_launch_gemm8(hipStream_t s, bool out_f32, const GemmArgs& g);
+// wh_gemm8_mx.hip: e4m3 x e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4 (out: 0 bf16, 1 f32, 2 MX codes + exponents), and the
+// LayerNorm that produces MX activations
+bool wh_gemm8_mx_applicable(const GemmArgs& g);
+void wh_launch_gemm8_mx(hipStream_t s, int out, const GemmArgs& g);
+void wh_launch_layernorm_mx(hipStream_t s, const float* x, const float* w, const float* b, void* codes, void* exps, long rows, int d);
 void wh_launch_layernorm(hipStream_t s, int prec, const float* x, const float* w, const float* b, void* y, long rows,
                          int d);
 void wh_launch_enc_attn(hipStream_t s, int prec, const void* qk, const void* vT, void* out, int n_clips, int S, int d,

@@ -538,25 +538,28 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     size_t o_conv2 = conv_reorder(T(e + ".conv2.weight"), d, d, 3 * d);
     size_t o_conv2b = st.put_f32(T(e + ".conv2.bias"), d);
     size_t o_encpos = st.put_f32(T(e + ".embed_positions.weight"), (size_t)c.n_audio_ctx * d);
-    struct EncOff { size_t qk, qkb, v, vb, o, ob, f1, f1b, f2, f2b, l1w, l1b, l2w, l2b, qksc, vsc, osc, f1sc, f2sc; };
+    struct EncOff { size_t qk, qkb, v, vb, o, ob, f1, f1b, f2, f2b, l1w, l1b, l2w, l2b, qksc, vsc, osc, f1sc, f2sc, qk8, v8, f18, f28; };
     // WH_PREC_FP8, encoder side: code values as a bf16 matrix + the row scales
-    auto put_q = [&](const float* W, size_t rows, size_t cols, size_t* sc_off) {
+    // (+ the raw codes for the fp8-MFMA kernel, wh_gemm8_mx.hip, when `raw8` is given)
+    auto put_q = [&](const float* W, size_t rows, size_t cols, size_t* sc_off, size_t* raw8 = nullptr) {
         QRows q;
         qrows(W, rows, cols, 1.0f, q, 0, rows);
         *sc_off = st.put_f32(q.scale.data(), rows);
+        if (raw8) *raw8 = st.put_bytes(q.codes.data(), q.codes.size());
         return st.put_codes_bf16(q, rows, cols);
     };
     std::vector<EncOff> eo(c.enc_layers);
     for (int i = 0; i < c.enc_layers; i++) {
         std::string p = e + ".layers." + std::to_string(i);
         EncOff& x = eo[i];
-        x.qksc = x.vsc = x.osc = x.f1sc = x.f2sc = NONE;
+        x.qksc = x.vsc = x.osc = x.f1sc = x.f2sc = x.qk8 = x.v8 = x.f18 = x.f28 = NONE;
         if (f8) {
             QRows q;
             qrows(T(p + ".self_attn.q_proj.weight"), d, d, qs, q, 0, 2 * d);
             qrows(T(p + ".self_attn.k_proj.weight"), d, d, 1.0f, q, d, 2 * d);
             x.qk = st.put_codes_bf16(q, 2 * d, d);
             x.qksc = st.put_f32(q.scale.data(), 2 * d);
+            x.qk8 = st.put_bytes(q.codes.data(), q.codes.size());
         } else {
             x.qk = st.reserve(2 * d * d * m->esz);
             for (size_t r = 0; r < d; r++) {
@@ -567,13 +570,13 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
         tmp.assign(2 * d, 0.0f);
         for (size_t r = 0; r < d; r++) tmp[r] = T(p + ".self_attn.q_proj.bias")[r] * qs;
         x.qkb = st.put_f32(tmp.data(), 2 * d);
-        x.v = f8 ? put_q(T(p + ".self_attn.v_proj.weight"), d, d, &x.vsc) : st.put_mat(T(p + ".self_attn.v_proj.weight"), d, d, d);
+        x.v = f8 ? put_q(T(p + ".self_attn.v_proj.weight"), d, d, &x.vsc, &x.v8) : st.put_mat(T(p + ".self_attn.v_proj.weight"), d, d, d);
         x.vb = st.put_f32(T(p + ".self_attn.v_proj.bias"), d);
         x.o = f8 ? put_q(T(p + ".self_attn.out_proj.weight"), d, d, &x.osc) : st.put_mat(T(p + ".self_attn.out_proj.weight"), d, d, d);
         x.ob = st.put_f32(T(p + ".self_attn.out_proj.bias"), d);
-        x.f1 = f8 ? put_q(T(p + ".fc1.weight"), F, d, &x.f1sc) : st.put_mat(T(p + ".fc1.weight"), F, d, d);
+        x.f1 = f8 ? put_q(T(p + ".fc1.weight"), F, d, &x.f1sc, &x.f18) : st.put_mat(T(p + ".fc1.weight"), F, d, d);
         x.f1b = st.put_f32(T(p + ".fc1.bias"), F);
-        x.f2 = f8 ? put_q(T(p + ".fc2.weight"), d, F, &x.f2sc) : st.put_mat(T(p + ".fc2.weight"), d, F, F);
+        x.f2 = f8 ? put_q(T(p + ".fc2.weight"), d, F, &x.f2sc, &x.f28) : st.put_mat(T(p + ".fc2.weight"), d, F, F);
         x.f2b = st.put_f32(T(p + ".fc2.bias"), d);
         x.l1w = st.put_f32(T(p + ".self_attn_layer_norm.weight"), d);
         x.l1b = st.put_f32(T(p + ".self_attn_layer_norm.bias"), d);
@@ -629,6 +632,7 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     tmp.assign(Ld * 2 * d, 0.0f);
     std::vector<float> ckvb(Ld * 2 * d, 0.0f);
     std::vector<float> ckvsc(Ld * 2 * d, 1.0f);
+    std::vector<uint8_t> ckv8(f8 ? Ld * 2 * d * d : 0);   // WH_PREC_FP8: the stacked cross K/V projection rows as raw e4m3 codes
     for (int i = 0; i < c.dec_layers; i++) {
         std::string p = dd + ".layers." + std::to_string(i);
         DecOff& x = dof[i];
@@ -665,6 +669,8 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
                 for (size_t k = 0; k < d; k++) { rowk[k] = wh_e4m3_to_f32(qk.codes[r * d + k]); rowv[k] = wh_e4m3_to_f32(qv.codes[r * d + k]); }
                 st.put_row(o_ckv, ((size_t)i * 2 + 0) * d + r, d, rowk.data(), d, 1.0f);
                 st.put_row(o_ckv, ((size_t)i * 2 + 1) * d + r, d, rowv.data(), d, 1.0f);
+                memcpy(ckv8.data() + (((size_t)i * 2 + 0) * d + r) * d, qk.codes.data() + r * d, d);
+                memcpy(ckv8.data() + (((size_t)i * 2 + 1) * d + r) * d, qv.codes.data() + r * d, d);
                 ckvsc[((size_t)i * 2 + 0) * d + r] = qk.scale[r];
                 ckvsc[((size_t)i * 2 + 1) * d + r] = qv.scale[r];
                 ckvb[((size_t)i * 2 + 1) * d + r] = T(p + ".encoder_attn.v_proj.bias")[r];
@@ -715,6 +721,7 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     }
     size_t o_ckvb = st.put_f32(ckvb.data(), ckvb.size());
     size_t o_ckvsc = f8 ? st.put_f32(ckvsc.data(), ckvsc.size()) : NONE;
+    size_t o_ckv8 = f8 ? st.put_bytes(ckv8.data(), ckv8.size()) : NONE;
     size_t o_dlnw = st.put_f32(T(dd + ".layer_norm.weight"), d), o_dlnb = st.put_f32(T(dd + ".layer_norm.bias"), d);
     // LM head = tied embedding with the final LayerNorm folded in (a second copy: the plain one stays the lookup table)
     // (WH_PREC_FP8: γ sits on the activation side, so the lookup table itself is the operand)
@@ -770,6 +777,7 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
         EncOff& x = eo[i];
         m->enc[i] = EncLayerDev{P(x.qk), P(x.v), P(x.o), P(x.f1), P(x.f2), PF(x.qkb), PF(x.vb), PF(x.ob), PF(x.f1b),
                                 PF(x.f2b), PF(x.l1w), PF(x.l1b), PF(x.l2w), PF(x.l2b)};
+        if (f8) { m->enc[i].qk_w8 = P(x.qk8); m->enc[i].v_w8 = P(x.v8); m->enc[i].fc1_w8 = P(x.f18); m->enc[i].fc2_w8 = P(x.f28); }
         if (f8) { m->enc[i].qk_sc = PF(x.qksc); m->enc[i].v_sc = PF(x.vsc); m->enc[i].o_sc = PF(x.osc); m->enc[i].fc1_sc = PF(x.f1sc); m->enc[i].fc2_sc = PF(x.f2sc); }
     }
     m->enc_ln_w = PF(o_elnw); m->enc_ln_b = PF(o_elnb);
@@ -786,7 +794,7 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
         }
     }
     m->cross_kv_w = P(o_ckv); m->cross_kv_b = PF(o_ckvb);
-    if (f8) m->cross_kv_sc = PF(o_ckvsc);
+    if (f8) { m->cross_kv_sc = PF(o_ckvsc); m->cross_kv_w8 = P(o_ckv8); }
     m->dec_ln_w = PF(o_dlnw); m->dec_ln_b = PF(o_dlnb);
     m->lm_w = P(o_lmw); m->lm_s = PF(o_lms); m->lm_c = PF(o_lmc);
     m->mel_tw = (double*)P(o_tw); m->mel_win = PF(o_win); m->mel_fbT = PF(o_fb);
