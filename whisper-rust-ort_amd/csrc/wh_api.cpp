@@ -646,6 +646,8 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
     c->mpad = (int)align_up(B, 16);
     // enough workgroups to cover the chip at small batch, no more than 16 key ranges
     c->cross_splits = (int)std::min<size_t>(32, std::max<size_t>(1, 256 / B));  // measured: ~256 workgroups streams best
+    if (m->prec == WH_PREC_BF16 && d > 512 && d % 256 == 0)   // wide models: a workgroup per 256-column group as well (k_dec_cross_attn_cg)
+        c->cross_splits = (int)std::min<size_t>(32, std::max<size_t>(1, 512 / (B * (d / 256))));
     const size_t n_tiles = (D.vocab + 15) / 16;
     Carver cv;
     const size_t o_pcm = cv.take(B * WH_CLIP_SAMPLES * 4), o_raw = cv.take(B * C * RAW_LD * 4);

@@ -21,6 +21,8 @@
 //
 // [3P] decoder definition: modeling_whisper.py WhisperDecoderLayer.forward (:466-500), learned
 // positions offset by the past length (:208-212), final LN (:790), tied LM head, no bias (:965,970).
+#include <stdlib.h>
+
 #include "wh_common.h"
 #include "wh_kernels.h"
 
@@ -934,6 +936,117 @@ __global__ __launch_bounds__(256) void k_dec_cross_attn(const T* __restrict__ q,
     }
 }
 
+// ---- the same for wide models (d_model > 512, bf16): one workgroup = one clip x one key range x one COLUMN GROUP of
+// 256 columns (4 heads).  With all heads in one workgroup a d = 1280 row needs 2.5 wave-instructions (three chunks per
+// lane, a sixth of the lanes idle in the last) and the register sets allow only two keys in flight per wave: 0.42 of the
+// HBM roof at whisper-large-v3 width.  Here a wave-instruction reads the 512-byte segments of TWO key rows (lanes 0-31 the
+// even key, 32-63 the odd key of a pair), UNROLL pairs per register set, two sets: the base kernel's 16 KiB in flight per
+// wave, every lane busy.  The two parities of a wave keep separate online-softmax states; 4 waves x 2 parities merge
+// through LDS.  Output layout unchanged (partials [B][splits][d], {max, sum} [B][splits][H][2], or the slab when splits == 1).
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void k_dec_cross_attn_cg(const bf16* __restrict__ q, const bf16* __restrict__ ck,
+                                                           const bf16* __restrict__ cv, float* __restrict__ part,
+                                                           float* __restrict__ ml, int S, int d, int n_heads,
+                                                           int splits, bf16* __restrict__ out, int mpad) {
+    constexpr int CGW = 256, HPG = CGW / WH_HEAD_DIM;   // columns / heads per group
+    __shared__ __attribute__((aligned(16))) float wm[8][HPG], wl[8][HPG], wo[8][CGW];
+    typedef __attribute__((ext_vector_type(8))) bf16 vec_t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int par = lane >> 5, chunk = lane & 31;
+    const int sp = blockIdx.x, b = blockIdx.y, cg = blockIdx.z;
+    const int per = (S + splits - 1) / splits;
+    const int ks = sp * per, j1 = min(S, ks + per);
+    const int col0 = cg * CGW + chunk * 8;
+    const wh_u32x4 qd = *reinterpret_cast<const wh_u32x4*>(q + (long)b * d + col0);
+    float o[8], mrun = -INFINITY, lrun = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = 0.0f;
+    const bf16* kb = ck + (long)b * S * d + col0;
+    const bf16* vb = cv + (long)b * S * d + col0;
+    vec_t kA[UNROLL], vA[UNROLL], kB[UNROLL], vB[UNROLL];
+    auto load_set = [&](vec_t (&kk)[UNROLL], vec_t (&vv)[UNROLL], int j) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const int jj = min(j + 2 * u + par, j1 - 1);   // tail: re-read the last key, masked in compute_set
+            if constexpr (NT) {
+                kk[u] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(kb + (long)jj * d));
+                vv[u] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(vb + (long)jj * d));
+            } else {
+                kk[u] = *reinterpret_cast<const vec_t*>(kb + (long)jj * d);
+                vv[u] = *reinterpret_cast<const vec_t*>(vb + (long)jj * d);
+            }
+        }
+    };
+    auto compute_set = [&](const vec_t (&kk)[UNROLL], const vec_t (&vv)[UNROLL], int j) {
+        float s[UNROLL];
+        float mx = mrun;
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            float t = dot8_bf16(as_u32x4(kk[u]), qd, 0.0f);
+            t = dpp_group_sum<8>(t);
+            s[u] = (j + 2 * u + par < j1) ? t : -INFINITY;
+            mx = fmaxf(mx, s[u]);
+        }
+        const float scale = (mx == -INFINITY) ? 1.0f : __expf(mrun - mx);   // nothing seen yet (this parity's keys all masked): keep zeros
+        float ls = lrun * scale;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] *= scale;
+#pragma unroll
+        for (int u = 0; u < UNROLL; u += 2) {
+            const float p0 = (s[u] == -INFINITY) ? 0.0f : __expf(s[u] - mx), p1 = (s[u + 1] == -INFINITY) ? 0.0f : __expf(s[u + 1] - mx);
+            ls += p0 + p1;
+            const bf16x2 pp = bf16x2{(bf16)p0, (bf16)p1};
+            const wh_u32x4 va = as_u32x4(vv[u]), vb2 = as_u32x4(vv[u + 1]);
+            pv2_bf16(va.x, vb2.x, pp, o[0], o[1]);
+            pv2_bf16(va.y, vb2.y, pp, o[2], o[3]);
+            pv2_bf16(va.z, vb2.z, pp, o[4], o[5]);
+            pv2_bf16(va.w, vb2.w, pp, o[6], o[7]);
+        }
+        mrun = mx;
+        lrun = ls;
+    };
+    constexpr int GS = 4 * UNROLL * 2;   // keys per round of the four waves
+    const int j0 = ks + wave * UNROLL * 2;
+    if (j0 < j1) load_set(kA, vA, j0);
+    for (int j = j0; j < j1; j += 2 * GS) {
+        const bool hasB = j + GS < j1;
+        if (hasB) load_set(kB, vB, j + GS);
+        compute_set(kA, vA, j);
+        if (hasB) {
+            if (j + 2 * GS < j1) load_set(kA, vA, j + 2 * GS);
+            compute_set(kB, vB, j + GS);
+        }
+    }
+    // merge the 4 waves x 2 parities of this key range (LDS)
+    const int st = wave * 2 + par;
+    if ((chunk & 7) == 0) { wm[st][chunk >> 3] = mrun; wl[st][chunk >> 3] = lrun; }
+#pragma unroll
+    for (int e = 0; e < 8; e++) wo[st][chunk * 8 + e] = o[e];
+    __syncthreads();
+    float* pp = part + ((long)b * splits + sp) * d + cg * CGW;
+    float* mp = ml + ((long)b * splits + sp) * n_heads * 2;
+    {
+        const int n = tid, hl = n / WH_HEAD_DIM, h = cg * HPG + hl;   // 256 threads = 256 columns of the group
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 8; w++) M = fmaxf(M, wm[w][hl]);
+        float num = 0.0f, den = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const float mw = wm[w][hl];
+            const float sc = (mw == -INFINITY) ? 0.0f : __expf(mw - M);   // a stream may own no keys
+            num += sc * wo[w][n];
+            den += sc * wl[w][hl];
+        }
+        if (out) {
+            out[slab_idx(b, cg * CGW + n, mpad)] = (bf16)(num / den);
+        } else {
+            pp[n] = num;
+            if ((n % WH_HEAD_DIM) == 0) { mp[h] = M; mp[n_heads + h] = den; }
+        }
+    }
+}
+
 // raise a kernel's dynamic-LDS limit once per (device, kernel, size)
 template <typename K>
 void set_max_smem(K kernel, size_t bytes) {
@@ -1020,6 +1133,9 @@ void launch_lm_head_t(hipStream_t s, const SkinnyArgs& a, int* n_parts_out = nul
     int mt = std::min(wh_dbg_lm_mt, (a.M + 15) / 16);
     auto lds = [&](int t) { return (size_t)t * 16 * a.K * sizeof(T) + (size_t)t * 16 * 2 * 4 * 5; };  // X tile + LN stats (+ 4 quarter sums)
     while (mt > 1 && lds(mt) > 150 * 1024) mt--;
+    // (128-row groups — two instead of four at 256 clips, half the passes over the 53 MB embedding but one workgroup per CU —
+    // measured no faster: 189.5 vs 188.0 ms per 256-clip step)
+    if (mt > 4) mt = 4;
     const size_t sm = lds(mt);
     const int per_cu = std::max<int>(1, (int)(150 * 1024 / sm));
     dim3 grid(std::min((n_tiles + 3) / 4, 256 * std::min(per_cu, wh_dbg_lm_blocks_per_cu) / ((a.M + 16 * mt - 1) / (16 * mt))), (a.M + 16 * mt - 1) / (16 * mt));
@@ -1083,7 +1199,12 @@ void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void
     } else {
         const int nch = (d / 8 + 63) / 64;
         if (nch == 1) { if (wh_dbg_cross_unroll == 8) WH_CA(bf16, 1, 8); else WH_CA(bf16, 1, 4); }
-        else WH_CA(bf16, 3, 2);
+        else if (d % 256 == 0 && getenv("WH_CROSS_ALLHEADS") == nullptr) {   // wide models: one workgroup per 256-column group
+            dim3 g3(splits, B, d / 256);
+            bf16* o = (bf16*)(splits == 1 ? out : nullptr);
+            if (stream_nt) hipLaunchKernelGGL((k_dec_cross_attn_cg<4, true>), g3, dim3(256), 0, s, (const bf16*)q, (const bf16*)ck, (const bf16*)cv, part, ml, S, d, n_heads, splits, o, mpad);
+            else hipLaunchKernelGGL((k_dec_cross_attn_cg<4, false>), g3, dim3(256), 0, s, (const bf16*)q, (const bf16*)ck, (const bf16*)cv, part, ml, S, d, n_heads, splits, o, mpad);
+        } else WH_CA(bf16, 3, 2);
     }
 #undef WH_CA
 #undef WH_CA1
