@@ -35,6 +35,7 @@ int wh_dbg_cross_unroll = 4;
 int wh_dbg_lm_blocks_per_cu = 2;
 int wh_dbg_lm_mt = 4;
 int wh_dbg_mt = 0;
+int wh_dbg_nw = 0;   // 4 / 8: force the K split of the decode GEMM (0 = heuristic)
 
 namespace {
 
@@ -1100,7 +1101,8 @@ void launch_dec_gemm_split(hipStream_t s, const SkinnyArgs& a) {
     // K is split over the waves of a workgroup: 8 ways when it is deep, else 4 (K % 128 == 0 always
     // holds: d_model and ffn are multiples of 128, checked at model load)
     // (X from attention partials: 8 ways too — fewer fragments to merge per lane)
-    if (dec_gemm_8way(a)) launch_dec_gemm_mt<T, TO, 8, TW>(s, a);
+    const bool eight = wh_dbg_nw ? (wh_dbg_nw == 8 && a.K % 256 == 0) : dec_gemm_8way(a);
+    if (eight) launch_dec_gemm_mt<T, TO, 8, TW>(s, a);
     else launch_dec_gemm_mt<T, TO, 4, TW>(s, a);
 }
 

@@ -146,4 +146,5 @@ void wh_launch_dec_cross_attn8(hipStream_t s, const void* q, const void* ck, con
 extern int wh_dbg_cross_unroll;
 extern int wh_dbg_lm_blocks_per_cu;
 extern int wh_dbg_mt;
+extern int wh_dbg_nw;
 extern int wh_dbg_lm_mt;
