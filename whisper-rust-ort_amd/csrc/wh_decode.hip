@@ -1063,6 +1063,9 @@ void launch_dec_gemm_mt(hipStream_t s, const SkinnyArgs& a) {
     // measured (tools/microbench.cpp, M = 64): N = 512 → 16 rows best (2.6 vs 3.7 us), N = 1536 / 2048 → 32 rows
     // (2.95 vs 3.5 us), K = 2048 → 16 rows (4.6 vs 7.5 us): aim for >= 128 workgroups
     int mt_cap = (NW == 8 || n_tiles <= 48) ? 1 : 2;
+    // wide models (K >= 1024: weights stream from HBM, profiles/r02_dec_gemm_wide_m32.txt): 32-row groups only for the 8-way
+    // split of a wide N (QKV: 6.9 vs 7.6 us); everything else 16 rows (fc1 9.9 vs 10.5 us, N = 1280 4.6 vs 5.3 us)
+    if (a.K >= 1024) mt_cap = (NW == 8 && n_tiles > 96) ? 2 : 1;
     if (wh_dbg_mt > 0) mt_cap = wh_dbg_mt;  // microbench override
     // batches beyond 64 rows (measured at 256 clips): 64-row groups for the 4-way K split — the row groups already give
     // hundreds of workgroups, and each weight fragment then feeds four MFMAs instead of one or two (-0.7 % step time)
@@ -1092,8 +1095,10 @@ void launch_dec_gemm_mt(hipStream_t s, const SkinnyArgs& a) {
 // launch would otherwise put fewer than ~128 workgroups on the chip (small batch x narrow N: more waves per
 // workgroup keep more weight bytes in flight per CU); else 4.  Needs K % 256 == 0.
 static inline bool dec_gemm_8way(const SkinnyArgs& a) {
-    const long wgs = (long)((a.N + 15) / 16) * ((a.M + 15) / 16);
-    return (a.K >= 2048 || a.xpart || (wgs < 128 && a.K >= 1024)) && a.K % 256 == 0;
+    // (K >= 1024, N <= 4096: eight waves per workgroup keep twice the weight bytes in flight per CU — 4.6 vs 5.8 us for
+    // N = K = 1280 at 32 rows, 5.7 vs 6.5 us for the QKV projection; the widest N has enough workgroups without it.
+    // The choice never depends on the batch: a batch must not change the summation order of a row)
+    return (a.K >= 2048 || a.xpart || (a.K >= 1024 && a.N <= 4096)) && a.K % 256 == 0;
 }
 
 template <typename T, typename TO, typename TW>
