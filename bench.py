@@ -143,7 +143,12 @@ def self_launch(n: int) -> int:
         for pr in procs:
             if pr.poll() is None:
                 pr.kill()
-    sys.stdout.write(out0.decode(errors="replace"))
+    # rank 0's stdout may carry library chatter (gloo prints its connection banner there): relay the JSON line(s) only
+    for line in out0.decode(errors="replace").splitlines():
+        if line.startswith("{"):
+            sys.stdout.write(line + "\n")
+        elif line.strip():
+            print(line, file=sys.stderr)
     sys.stdout.flush()
     return rc
 
@@ -351,13 +356,17 @@ def main() -> None:
         avg_s = live["ms"] * 1e-3 / max(1, live["launches"])
         ach = work["cross_attn_bytes_per_launch"] / avg_s / 1e9
         traffic = None
+        # the dominant kernel's variants: e4m3 cache (fp8 mode), one workgroup per 256-column group (wide models), all heads per workgroup
+        dom_kernel = ("k_dec_cross_attn8" if prec == wb.WH_PREC_FP8 else
+                      "k_dec_cross_attn_cg" if (prec == wb.WH_PREC_BF16 and dims.d_model > 512 and dims.d_model % 256 == 0) else "k_dec_cross_attn")
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):   # HBM bytes per launch from rocprofv3 --pmc passes (see profiles/README.md)
             tj = json.load(open(tpath))
             key = f"{a.preset}_{a.precision}_b{per_stream}"
-            traffic = tj.get("k_dec_cross_attn8" if prec == wb.WH_PREC_FP8 else "k_dec_cross_attn", {}).get(key)
+            traffic = tj.get(dom_kernel, {}).get(key)
         roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": traffic, "kernel": "k_dec_cross_attn8" if prec == wb.WH_PREC_FP8 else "k_dec_cross_attn", "avg_launch_us": avg_s * 1e6,
+                    "traffic": traffic, "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/pmc_traffic.json (profiles/collect.sh)",
+                    "kernel": dom_kernel, "avg_launch_us": avg_s * 1e6,
                     "launches_timed": live["launches"], "alg_bytes_per_launch": work["cross_attn_bytes_per_launch"],
                     "share_of_kernel_time": breakdown["dec_cross_attn"]["ms"] / tot_ms}
         d_, F_, T_, Le_ = dims.d_model, dims.ffn, dims.n_audio_ctx, dims.enc_layers
@@ -372,9 +381,9 @@ def main() -> None:
             "enc_attn": sec("mfma", attn_flop, breakdown["enc_attn"]["ms"], mfma_peak, "TFLOP/s",
                             "k_enc_attn; VALU-bound below the MFMA roof (one v_exp_f32 per 256 MFMA flops at head_dim 64)"),
             "enc_gemm": sec("mfma", gemm_flop, breakdown["enc_gemm"]["ms"], mfma_peak, "TFLOP/s",
-                            "k_gemm (Conv1d-as-GEMM, QK, V^T, out-proj, fc1, fc2); the group's time also holds the 13 encoder LayerNorm launches"),
+                            "k_gemm8 / k_gemm8_mx (Conv1d-as-GEMM, QK, V^T, out-proj, fc1, fc2); the group's time also holds the 13 encoder LayerNorm launches"),
             "mel": sec("hbm", work["mel_bytes_per_clip"] * a.clips, breakdown["mel"]["ms"], HBM_PEAK_GBS, "GB/s",
-                       "k_mel_stft + k_mel_tokens; in practice f64-MFMA-issue bound (DFT on the f64 matrix cores)"),
+                       "k_mel_stft (mixed-radix FFT in LDS + f32-MFMA filterbank) + k_mel_tokens; latency-bound per 16-frame workgroup"),
         }
         out = {
             "metric": "rtfx: audio seconds transcribed per wall second (whisper-base, 30 s clips, greedy 128 new tokens)",
