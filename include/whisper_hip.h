@@ -118,6 +118,7 @@ int wh_model_precision(const wh_model* m);
 int wh_model_export_tensor(const wh_model* m, const char* name, float* out, size_t cap, size_t* n_out);
 
 /* ---- per-stream context: workspace + KV cache for up to max_batch clips in flight ------------- */
+#define WH_MAX_BATCH 1024   /* largest max_batch wh_ctx_create accepts */
 int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out);
 void wh_ctx_free(wh_ctx* c);
 const char* wh_last_error(const wh_ctx* c); /* c == NULL: last load/create error of this thread */

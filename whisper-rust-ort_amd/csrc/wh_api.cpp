@@ -632,7 +632,7 @@ int wh_model_export_tensor(const wh_model* m, const char* name, float* out, size
 int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
     if (!m || !out) { wh_set_error("wh_ctx_create: NULL argument"); return WH_ERR_ARG; }
     *out = nullptr;
-    if (max_batch < 1 || max_batch > 256) { wh_set_error("max_batch must be 1..256"); return WH_ERR_ARG; }
+    if (max_batch < 1 || max_batch > WH_MAX_BATCH) { wh_set_error("max_batch must be 1..1024"); return WH_ERR_ARG; }
     WH_HIP_CHECK(hipSetDevice(m->device));
     auto* c = new wh_ctx();
     c->m = m;
