@@ -48,6 +48,9 @@ _cache = {}
 def bundle(preset, seed, prec, max_batch=1):
     k = (preset, seed, prec, max_batch)
     if k not in _cache:
+        if max_batch > 256:      # tens of GB of workspace each: keep one at a time
+            for kk in [kk for kk in _cache if kk[3] > 256]:
+                _cache.pop(kk).ctx.close()
         _cache[k] = Bundle(preset, seed, prec, max_batch)
     return _cache[k]
 
@@ -481,3 +484,25 @@ def test_f32_base_batched_contexts_match_golden(gpu, golden_dir, nb):
             np.testing.assert_allclose(lc[r][:4, :2048], g[c]["logits_c_head"], rtol=0, atol=LOGIT_TOL)
     print(f"f32 base, {nb}-clip context: max |logit - golden| over all compared rows {worst:.2e}")
     assert worst <= LOGIT_TOL
+
+
+@pytest.mark.parametrize("prec_name", ["bf16", "fp8"])
+def test_wide_batch_decode_gemm_is_bit_identical(gpu, monkeypatch, prec_name):
+    """k_dec_gemm_wide (several 16-column tiles per workgroup, chosen from the batch size) against k_dec_gemm on the same
+    512-clip context: same K split, same summation order — tokens and every logit bit-identical, whichever tile count runs."""
+    prec = wb.PRECISIONS[prec_name]
+    model = wb.Model("synthetic:base:1234", 0, prec)
+    prompt, eot = [50258, 50259, 50359, 50363], 50257
+    clips = [ms.synth_clip(700 + i) for i in range(8)]
+    forced = np.random.Generator(np.random.PCG64(11)).integers(0, 50257, size=5).tolist()
+    res = {}
+    for wide in ("0", "-1", "2", "4"):
+        monkeypatch.setenv("WH_DEC_WIDE", wide)
+        ctx = wb.Context(model, 512)
+        toks = [t.tolist() for t in ctx.transcribe_batch([clips[i % 8] for i in range(512)], wb.DecodeParams(prompt, 24, eot, [eot]))]
+        _, lg = ctx.greedy_decode_resident_batch(wb.DecodeParams(prompt, len(forced) + 1, eot, forced=forced), want_logits=True)
+        res[wide] = (toks, np.stack(lg))
+        ctx.close()
+    for wide in ("-1", "2", "4"):
+        assert res[wide][0] == res["0"][0], wide
+        assert np.array_equal(res[wide][1], res["0"][1]), wide

@@ -36,6 +36,7 @@ int wh_dbg_lm_blocks_per_cu = 2;
 int wh_dbg_lm_mt = 4;
 int wh_dbg_mt = 0;
 int wh_dbg_nw = 0;   // 4 / 8: force the K split of the decode GEMM (0 = heuristic)
+int wh_dbg_wide = -1;  // column tiles per workgroup at > 256 rows: -1 heuristic, 0 off (k_dec_gemm only), 2 / 4 forced
 
 namespace {
 
@@ -372,6 +373,166 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
         if (fg == 0 && em < a.M) {
             a.stats_out[((long)blockIdx.x * a.x_mpad + em) * 2] = s1;
             a.stats_out[((long)blockIdx.x * a.x_mpad + em) * 2 + 1] = s2;
+        }
+    }
+    advance_if_last(a.ticket, a.pos_w, gridDim.x * gridDim.y);
+}
+
+// Batches of hundreds of rows: a workgroup owns NT 16-column tiles x MT 16-row tiles, so every activation fragment a wave
+// loads feeds NT MFMAs and every weight fragment MT (k_dec_gemm at NT = 1 pulls the activations through L2 once per 16
+// output columns: 123 MB for the 1536 x 512 QKV projection at 1024 rows, 49 MB here).  Same K split over the waves, same
+// k order inside a wave and the same order of the cross-wave sum as k_dec_gemm: an output element is bit-identical
+// whichever of the two computes it, so the choice may follow the batch.  Wave w finishes tiles w, w + NW, ...
+// (tile id = nt * MT + mt).  No merged-X (attention partials) variant: large batches run one key range per clip.
+template <typename T, typename TO, int MT, int NT, int NW, typename TW = T>
+__global__ __launch_bounds__(NW * 64, 2) void k_dec_gemm_wide(SkinnyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fl = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * 16 * NT;
+    const int m0 = blockIdx.y * MT * 16;
+    constexpr int KW = WTraits<T, TW>::KW, SUB = KW / 8, KSTEP = 4 * KW;
+    constexpr int TILES = MT * NT, TPW = (TILES + NW - 1) / NW;
+    const int kspan = a.K / NW, kb = wave * kspan, iters = kspan / KSTEP;
+    const TW* wp[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) wp[nt] = (const TW*)a.W + (long)min(n0 + nt * 16 + fl, a.N - 1) * a.K + kb + fg * KW;
+    const long xstep = (long)a.x_mpad * 32 * (KSTEP / 32);
+    const T* xp = (const T*)a.X + ((long)((kb + fg * KW) >> 5) * a.x_mpad + m0 + fl) * 32 + ((fg * KW) & 31);
+    constexpr int DEPTH = 4 / SUB;  // four 32-deep k-slabs in flight per wave: (NT + MT) KiB each
+    typename FragT<T>::type wq[DEPTH][NT][SUB], xq[DEPTH][SUB][MT];
+#pragma unroll
+    for (int i = 0; i < DEPTH; i++)
+        if (i < iters) {
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) load_wfrags<T, TW>(wp[nt] + i * KSTEP, wq[i][nt]);
+#pragma unroll
+            for (int j = 0; j < SUB; j++)
+#pragma unroll
+                for (int t = 0; t < MT; t++) xq[i][j][t] = load_frag<T>(xp + i * xstep + t * 512 + 8 * j);
+        }
+    // the tiles this wave finishes; their residual rows are fetched now, the per-column operands after the main loop
+    int en[TPW], em[TPW];
+    bool ep_ok[TPW];
+    f32x4 pre_r[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; j++) {
+        const int t = wave + j * NW;
+        en[j] = n0 + (t / MT) * 16 + 4 * fg;
+        em[j] = m0 + (t % MT) * 16 + fl;
+        ep_ok[j] = t < TILES && en[j] < a.N && em[j] < a.M;
+        pre_r[j] = f32x4{0, 0, 0, 0};
+        if (ep_ok[j] && a.R) pre_r[j] = *reinterpret_cast<const f32x4*>(a.R + (long)em[j] * a.ldr + en[j]);
+    }
+    float* lnred = reinterpret_cast<float*>(smem_raw) + (size_t)NW * TILES * 64 * 4;  // [4][MT*16][2]
+    if (a.ln_part) {
+        constexpr int ROWS = MT * 16;
+        static_assert(4 * ROWS <= NW * 64, "one thread per (quarter, row)");
+        if (tid < 4 * ROWS) {
+            const int r = tid % ROWS, q = tid / ROWS;
+            float s1, s2;
+            ln_partial_sum(a.ln_part, a.ln_tiles, a.x_mpad, m0 + r, q, 4, s1, s2);
+            lnred[(q * ROWS + r) * 2] = s1;
+            lnred[(q * ROWS + r) * 2 + 1] = s2;
+        }
+    }
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int t = 0; t < MT; t++) acc[nt][t] = f32x4{0, 0, 0, 0};
+    for (int c0 = 0; c0 < iters; c0 += DEPTH) {
+        if (c0 > 0) {
+#pragma unroll
+            for (int i = 0; i < DEPTH; i++)
+                if (c0 + i < iters) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) load_wfrags<T, TW>(wp[nt] + (c0 + i) * KSTEP, wq[i][nt]);
+#pragma unroll
+                    for (int j = 0; j < SUB; j++)
+#pragma unroll
+                        for (int t = 0; t < MT; t++) xq[i][j][t] = load_frag<T>(xp + (c0 + i) * xstep + t * 512 + 8 * j);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < DEPTH; i++)
+            if (c0 + i < iters) {
+#pragma unroll
+                for (int j = 0; j < SUB; j++)
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                        for (int t = 0; t < MT; t++) mma16(acc[nt][t], wq[i][nt][j], xq[i][j][t]);
+            }
+    }
+    f32x4 pre_bias[TPW], pre_ws[TPW], pre_g[TPW], pre_sv[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; j++) {
+        pre_bias[j] = f32x4{0, 0, 0, 0}; pre_ws[j] = f32x4{1, 1, 1, 1}; pre_g[j] = f32x4{1, 1, 1, 1}; pre_sv[j] = f32x4{0, 0, 0, 0};
+        if (ep_ok[j]) {
+            if (a.bias) pre_bias[j] = *reinterpret_cast<const f32x4*>(a.bias + en[j]);
+            if (a.wscale) pre_ws[j] = *reinterpret_cast<const f32x4*>(a.wscale + en[j]);
+            if (a.xgamma) pre_g[j] = *reinterpret_cast<const f32x4*>(a.xgamma + en[j]);
+            if (a.ln_part) pre_sv[j] = *reinterpret_cast<const f32x4*>(a.ln_s + en[j]);
+        }
+    }
+    f32x4* red = reinterpret_cast<f32x4*>(smem_raw);
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int t = 0; t < MT; t++) red[(wave * TILES + nt * MT + t) * 64 + lane] = acc[nt][t];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TPW; j++) {
+        const int t = wave + j * NW;
+        if (t >= TILES) break;  // wave-uniform
+        f32x4 s = {0, 0, 0, 0};
+        float v[4] = {0, 0, 0, 0};
+        if (ep_ok[j]) {
+            s = red[(0 * TILES + t) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < NW; w++) {
+                f32x4 o = red[(w * TILES + t) * 64 + lane];
+                s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
+            }
+            float ln_mean = 0.0f, ln_rstd = 1.0f;
+            if (a.ln_part) {
+                constexpr int ROWS = MT * 16;
+                const int r = (t % MT) * 16 + fl;
+                const float s1 = (lnred[r * 2] + lnred[(ROWS + r) * 2]) + (lnred[(2 * ROWS + r) * 2] + lnred[(3 * ROWS + r) * 2]);
+                const float s2 = (lnred[r * 2 + 1] + lnred[(ROWS + r) * 2 + 1]) + (lnred[(2 * ROWS + r) * 2 + 1] + lnred[(3 * ROWS + r) * 2 + 1]);
+                ln_mean = s1 / (float)a.K;
+                ln_rstd = rsqrtf(fmaxf(s2 / (float)a.K - ln_mean * ln_mean, 0.0f) + 1e-5f);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float sc = s[e] * pre_ws[j][e];  // fp8 weights: the channel scale (1 otherwise)
+                v[e] = a.ln_part ? ln_rstd * (sc - ln_mean * pre_sv[j][e]) + pre_bias[j][e] : sc + pre_bias[j][e];
+                if (a.act == 1) v[e] = gelu_erf(v[e]);
+                v[e] += pre_r[j][e];
+            }
+            TO* dst = a.c_mpad ? (TO*)a.C + slab_idx(em[j], en[j], a.c_mpad) : (TO*)a.C + (long)em[j] * a.ldc + en[j];
+            store4(dst, v[0], v[1], v[2], v[3]);
+            if (a.xslab_out) store4((T*)a.xslab_out + slab_idx(em[j], en[j], a.x_mpad), v[0] * pre_g[j][0], v[1] * pre_g[j][1], v[2] * pre_g[j][2], v[3] * pre_g[j][3]);
+        }
+        if (a.stats_out) {
+            // this column tile's {sum x, sum x^2} per row (producers have no activation: v = s*ws + bias + r, as in k_dec_gemm)
+            float s1 = 0.0f, s2 = 0.0f;
+            if (ep_ok[j]) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float u = s[e] * pre_ws[j][e] + pre_bias[j][e] + pre_r[j][e];
+                    s1 += u;
+                    s2 += u * u;
+                }
+            }
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            if (fg == 0 && em[j] < a.M) {
+                const long tile = (long)blockIdx.x * NT + t / MT;
+                a.stats_out[(tile * a.x_mpad + em[j]) * 2] = s1;
+                a.stats_out[(tile * a.x_mpad + em[j]) * 2 + 1] = s2;
+            }
         }
     }
     advance_if_last(a.ticket, a.pos_w, gridDim.x * gridDim.y);
@@ -1071,6 +1232,25 @@ void launch_dec_gemm_mt(hipStream_t s, const SkinnyArgs& a) {
     // hundreds of workgroups, and each weight fragment then feeds four MFMAs instead of one or two (-0.7 % step time)
     if (wh_dbg_mt <= 0 && a.M > 64 && NW == 4) mt_cap = 4;
     if (wh_dbg_mt <= 0 && a.M > 64 && NW == 8 && !a.xpart) mt_cap = 2;  // fc2: 32-row groups (-0.5 %; 64 is slower again)
+    // hundreds of rows (one key range per clip, so no merged X): NT column tiles per workgroup while >= 256 workgroups remain
+    // (k_dec_gemm_wide; bit-identical results, so following the batch is allowed)
+    if constexpr (sizeof(T) == 2)   // (the exact-f32 mode keeps k_dec_gemm: its 8-register fragments do not fit NT x MT tiles)
+    if (a.M > 64 && !a.xpart && wh_dbg_mt <= 0 && a.K % (NW * 128) == 0) {
+        constexpr int WMT = 4;
+        int wide = wh_dbg_wide;
+        if (const char* e = getenv("WH_DEC_WIDE")) wide = atoi(e);   // A/B switch for the parity test (0: k_dec_gemm only)
+        const int rg = (a.M + 16 * WMT - 1) / (16 * WMT);
+        int nt = 4;
+        while (nt > 1 && (n_tiles % nt != 0 || (n_tiles / nt) * rg < 256)) nt >>= 1;
+        if (wide == 2 || wide == 4) nt = wide;
+        if (wide != 0 && nt > 1 && n_tiles % nt == 0) {
+            const size_t smw = (size_t)NW * WMT * nt * 64 * 16 + (size_t)4 * WMT * 16 * 2 * 4;
+            dim3 gw(n_tiles / nt, rg);
+            if (nt == 4) { set_max_smem(k_dec_gemm_wide<T, TO, WMT, 4, NW, TW>, smw); hipLaunchKernelGGL((k_dec_gemm_wide<T, TO, WMT, 4, NW, TW>), gw, dim3(NW * 64), smw, s, a); }
+            else { set_max_smem(k_dec_gemm_wide<T, TO, WMT, 2, NW, TW>, smw); hipLaunchKernelGGL((k_dec_gemm_wide<T, TO, WMT, 2, NW, TW>), gw, dim3(NW * 64), smw, s, a); }
+            return;
+        }
+    }
     const int mt = std::min(mt_cap, (a.M + 15) / 16);
     const size_t sm = (size_t)NW * mt * 64 * 16 + (size_t)4 * mt * 16 * 2 * 4;
     dim3 grid(n_tiles, (a.M + 16 * mt - 1) / (16 * mt));
