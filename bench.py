@@ -401,7 +401,7 @@ def main() -> None:
                        "k_mel_stft (mixed-radix FFT in LDS + f32-MFMA filterbank) + k_mel_tokens; latency-bound per 16-frame workgroup"),
         }
         out = {
-            "metric": "rtfx: audio seconds transcribed per wall second (whisper-base, 30 s clips, greedy 128 new tokens)",
+            "metric": f"rtfx: audio seconds transcribed per wall second (whisper-{a.preset}, 30 s clips, greedy {a.max_new_tokens} new tokens)",
             "value": audio_s / elapsed, "unit": "x real time", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.precision, "data": "synthetic",

@@ -441,21 +441,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_dec_gemm_wide(SkinnyArgs a) {
     for (int nt = 0; nt < NT; nt++)
 #pragma unroll
         for (int t = 0; t < MT; t++) acc[nt][t] = f32x4{0, 0, 0, 0};
+    // rolling prefetch: a slot is refilled with the k-slab DEPTH ahead as soon as its MFMAs are issued, so the next round's
+    // loads fly under this round's arithmetic instead of starting after it
     for (int c0 = 0; c0 < iters; c0 += DEPTH) {
-        if (c0 > 0) {
 #pragma unroll
-            for (int i = 0; i < DEPTH; i++)
-                if (c0 + i < iters) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; nt++) load_wfrags<T, TW>(wp[nt] + (c0 + i) * KSTEP, wq[i][nt]);
-#pragma unroll
-                    for (int j = 0; j < SUB; j++)
-#pragma unroll
-                        for (int t = 0; t < MT; t++) xq[i][j][t] = load_frag<T>(xp + (c0 + i) * xstep + t * 512 + 8 * j);
-                }
-        }
-#pragma unroll
-        for (int i = 0; i < DEPTH; i++)
+        for (int i = 0; i < DEPTH; i++) {
             if (c0 + i < iters) {
 #pragma unroll
                 for (int j = 0; j < SUB; j++)
@@ -464,6 +454,15 @@ __global__ __launch_bounds__(NW * 64, 2) void k_dec_gemm_wide(SkinnyArgs a) {
 #pragma unroll
                         for (int t = 0; t < MT; t++) mma16(acc[nt][t], wq[i][nt][j], xq[i][j][t]);
             }
+            if (c0 + DEPTH + i < iters) {
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) load_wfrags<T, TW>(wp[nt] + (c0 + DEPTH + i) * KSTEP, wq[i][nt]);
+#pragma unroll
+                for (int j = 0; j < SUB; j++)
+#pragma unroll
+                    for (int t = 0; t < MT; t++) xq[i][j][t] = load_frag<T>(xp + (c0 + DEPTH + i) * xstep + t * 512 + 8 * j);
+            }
+        }
     }
     f32x4 pre_bias[TPW], pre_ws[TPW], pre_g[TPW], pre_sv[TPW];
 #pragma unroll
@@ -1230,19 +1229,24 @@ void launch_dec_gemm_mt(hipStream_t s, const SkinnyArgs& a) {
     if (wh_dbg_mt > 0) mt_cap = wh_dbg_mt;  // microbench override
     // batches beyond 64 rows (measured at 256 clips): 64-row groups for the 4-way K split — the row groups already give
     // hundreds of workgroups, and each weight fragment then feeds four MFMAs instead of one or two (-0.7 % step time)
-    if (wh_dbg_mt <= 0 && a.M > 64 && NW == 4) mt_cap = 4;
+    if (wh_dbg_mt <= 0 && a.M > 64 && NW == 4) mt_cap = n_tiles <= 32 ? 2 : 4;   // (narrow N at 256 rows: 4.1 vs 4.8 us)
     if (wh_dbg_mt <= 0 && a.M > 64 && NW == 8 && !a.xpart) mt_cap = 2;  // fc2: 32-row groups (-0.5 %; 64 is slower again)
     // hundreds of rows (one key range per clip, so no merged X): NT column tiles per workgroup while >= 256 workgroups remain
     // (k_dec_gemm_wide; bit-identical results, so following the batch is allowed)
     if constexpr (sizeof(T) == 2)   // (the exact-f32 mode keeps k_dec_gemm: its 8-register fragments do not fit NT x MT tiles)
-    if (a.M > 64 && !a.xpart && wh_dbg_mt <= 0 && a.K % (NW * 128) == 0) {
+    if (a.M > 64 && !a.xpart && wh_dbg_mt <= 0 && a.K % (NW * 4 * WTraits<T, TW>::KW) == 0) {
         constexpr int WMT = 4;
         int wide = wh_dbg_wide;
         if (const char* e = getenv("WH_DEC_WIDE")) wide = atoi(e);   // A/B switch for the parity test (0: k_dec_gemm only)
         const int rg = (a.M + 16 * WMT - 1) / (16 * WMT);
-        int nt = 4;
-        while (nt > 1 && (n_tiles % nt != 0 || (n_tiles / nt) * rg < 256)) nt >>= 1;
-        if (wide == 2 || wide == 4) nt = wide;
+        // measured (tools/dec_gemm_sweep.cpp, profiles/r02_dec_gemm_sweep.txt): four column tiles while >= 512 workgroups
+        // remain (fc1 at 1024 rows: 11.7 vs 13.2 us), else two while >= 128 remain (1280 x 1280 at 256 rows: 8.5 vs 11.3 us;
+        // 512 x 512 at 256 rows would leave 64: 5.7 vs 4.1 us), else k_dec_gemm.  Eight waves x 16 tiles of partial sums
+        // would take 128 KB of LDS: two tiles at most there.
+        int nt = 1;
+        if (NW == 4 && n_tiles % 4 == 0 && (n_tiles / 4) * rg >= 512) nt = 4;
+        else if (n_tiles % 2 == 0 && (n_tiles / 2) * rg >= 128) nt = 2;
+        if (wide == 2 || (wide == 4 && NW == 4)) nt = wide;
         if (wide != 0 && nt > 1 && n_tiles % nt == 0) {
             const size_t smw = (size_t)NW * WMT * nt * 64 * 16 + (size_t)4 * WMT * 16 * 2 * 4;
             dim3 gw(n_tiles / nt, rg);
