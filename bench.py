@@ -400,6 +400,20 @@ def main() -> None:
             "mel": sec("hbm", work["mel_bytes_per_clip"] * a.clips, breakdown["mel"]["ms"], HBM_PEAK_GBS, "GB/s",
                        "k_mel_stft (mixed-radix FFT in LDS + f32-MFMA filterbank) + k_mel_tokens; latency-bound per 16-frame workgroup"),
         }
+        # rocprof-reported MFMA utilisation of the same configuration (profiles/collect_mfma.sh: SQ_VALU_MFMA_BUSY_CYCLES over
+        # GRBM_GUI_ACTIVE, i.e. matrix-pipe busy cycles over the SIMD cycles that actually elapsed — the shader clock under
+        # these kernels is 2.0-2.2 GHz, not the 2.4 GHz behind the 2.5 PFLOP/s peak; the calibration loop of nothing but MFMAs
+        # reads 0.68, profiles/r02_mfma_util_calibration.txt)
+        upath = os.path.join(ROOT, "profiles", "mfma_util.json")
+        if os.path.exists(upath):
+            uj = json.load(open(upath)).get(f"{a.preset}_{a.precision}_b{per_stream}", {})
+            def grp(prefixes):
+                ks = [k for k in uj if k.startswith(prefixes)]
+                busy = sum(uj[k]["mfma_util"] * uj[k]["total_ms_under_pmc"] * uj[k]["shader_clock_GHz"] for k in ks)
+                cyc = sum(uj[k]["total_ms_under_pmc"] * uj[k]["shader_clock_GHz"] for k in ks)
+                return {"mfma_util": busy / cyc, "kernels": {k: uj[k]["mfma_util"] for k in ks}} if cyc > 0 else None
+            secondary["enc_attn"]["rocprof"] = grp(("k_enc_attn",))
+            secondary["enc_gemm"]["rocprof"] = grp(("k_gemm8", "k_gemm<"))
         out = {
             "metric": f"rtfx: audio seconds transcribed per wall second (whisper-{a.preset}, 30 s clips, greedy {a.max_new_tokens} new tokens)",
             "value": audio_s / elapsed, "unit": "x real time", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
