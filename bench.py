@@ -402,8 +402,8 @@ def main() -> None:
         }
         # rocprof-reported MFMA utilisation of the same configuration (profiles/collect_mfma.sh: SQ_VALU_MFMA_BUSY_CYCLES over
         # GRBM_GUI_ACTIVE, i.e. matrix-pipe busy cycles over the SIMD cycles that actually elapsed — the shader clock under
-        # these kernels is 2.0-2.2 GHz, not the 2.4 GHz behind the 2.5 PFLOP/s peak; the calibration loop of nothing but MFMAs
-        # reads 0.68, profiles/r02_mfma_util_calibration.txt)
+        # these kernels is 2.0-2.2 GHz, not the 2.4 GHz behind the 2.5 PFLOP/s peak; a calibration loop of nothing but MFMAs
+        # reads 0.91-0.98 at 1.9-2.0 GHz, profiles/r02_mfma_util_calibration.txt)
         upath = os.path.join(ROOT, "profiles", "mfma_util.json")
         if os.path.exists(upath):
             uj = json.load(open(upath)).get(f"{a.preset}_{a.precision}_b{per_stream}", {})

@@ -9,9 +9,10 @@ summed over the 8 XCDs.  So with 256 CUs x 4 SIMDs
 
     util = sum(BUSY) / (sum(GUI_ACTIVE) / 8 * 1024)        # fraction of SIMD-cycles with the matrix pipe busy
 
-and sum(GUI_ACTIVE) / 8 / sum(duration) is the shader clock the kernel actually ran at (2.0 GHz under the calibration loop, not the
-2.4 GHz the 2.5 PFLOP/s figure assumes: `util` is against the cycles that happened, the bench line's flop/s fractions against the
-nominal peak).  The calibration loop itself — nothing but independent MFMAs, four waves per SIMD — reads 0.68.
+and sum(GUI_ACTIVE) / 8 / sum(duration) is the shader clock the kernel actually ran at.  The calibration loops — nothing but
+independent MFMAs, four to eight waves per SIMD — read 0.91-0.98 at a clock of 1.9-2.0 GHz, i.e. 1.9-2.0 PFLOP/s: under
+matrix load the part does not hold the 2.4 GHz behind the nominal 2.5 PFLOP/s.  `util` is against the cycles that happened,
+the bench line's flop/s fractions against the nominal peak.
 """
 import csv
 import collections

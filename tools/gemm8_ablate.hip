@@ -2,7 +2,9 @@
 // encoder's GEMM shapes (256 clips): full / no MFMA / no LDS-DMA in the loop / no epilogue / loads + barriers only.
 //   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -I whisper-rust-ort_amd/csrc tools/gemm8_ablate.hip -o tools/gemm8_ablate
 #include "../whisper-rust-ort_amd/csrc/wh_gemm8.hip"
+#include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 bool wh_ensure_dyn_lds(const void* k, size_t b) { return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b) == hipSuccess; }
 void wh_set_error(const char*, ...) {}
@@ -24,7 +26,62 @@ template <typename TO, int BN> void all(const char* name, const GemmArgs& g, dou
     printf("%-26s BN %3d: full %7.1f us (%5.0f TF/s) | no-mfma %7.1f | no-epilogue %7.1f | loads+barriers only %7.1f | no-stores %7.1f\n", name, BN, t0,
            gf / t0 * 1e3, t1, t4, t12, t16);
 }
+// correctness first: every geometry / output type / tail against a host double-precision product
+template <typename TO, int BN> double check_one(int M, int N, int K, bool resid, bool act, int bias_mode) {
+    std::vector<unsigned short> ha((size_t)M * K), hw((size_t)N * K);
+    std::vector<float> hr((size_t)M * N), hb(std::max(M, N)), hs(std::max(M, N));
+    unsigned x = 777u + M + N * 3 + K * 7;
+    auto rnd = [&]() { x = x * 1664525u + 1013904223u; return ((int)(x >> 9) % 2001 - 1000) * 1e-3f; };
+    auto tobf = [](float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); };
+    auto frombf = [](unsigned short b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; };
+    for (auto& v : ha) v = tobf(rnd());
+    for (auto& v : hw) v = tobf(rnd());
+    for (auto& v : hr) v = rnd();
+    for (auto& v : hb) v = rnd();
+    for (auto& v : hs) v = 0.5f + 0.25f * rnd();
+    bf16 *A, *W; float *R, *bias, *ws; TO* C;
+    hipMalloc(&A, ha.size() * 2); hipMalloc(&W, hw.size() * 2); hipMalloc(&R, hr.size() * 4); hipMalloc(&bias, hb.size() * 4); hipMalloc(&ws, hs.size() * 4);
+    hipMalloc(&C, (size_t)M * N * sizeof(TO)); hipMemset(C, 0xff, (size_t)M * N * sizeof(TO));
+    hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice); hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(R, hr.data(), hr.size() * 4, hipMemcpyHostToDevice); hipMemcpy(bias, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(ws, hs.data(), hs.size() * 4, hipMemcpyHostToDevice);
+    GemmArgs g; g.A = A; g.lda = K; g.W = W; g.ldw = K; g.C = C; g.ldc = N; g.bias = bias; g.wscale = ws; g.bias_mode = bias_mode; g.act = act; g.M = M; g.N = N; g.K = K;
+    if (resid) { g.R = R; g.ldr = N; }
+    run<TO, BN, 0>(g, 1);
+    std::vector<TO> hc((size_t)M * N);
+    hipMemcpy(hc.data(), C, hc.size() * sizeof(TO), hipMemcpyDeviceToHost);
+    double worst = 0;
+    for (int m = 0; m < M; m++)
+        for (int n = 0; n < N; n++) {
+            double acc = 0;
+            for (int k = 0; k < K; k++) acc += (double)frombf(ha[(size_t)m * K + k]) * frombf(hw[(size_t)n * K + k]);
+            const int bi = bias_mode == 2 ? m : n;
+            double v = acc * hs[bi] + hb[bi];
+            if (act) v = 0.5 * v * (1.0 + erf(v * 0.7071067811865476));
+            if (resid) v += hr[(size_t)m * N + n];
+            float got;
+            if constexpr (sizeof(TO) == 4) got = hc[(size_t)m * N + n]; else { unsigned short b; memcpy(&b, &hc[(size_t)m * N + n], 2); got = frombf(b); }
+            const double tol = sizeof(TO) == 4 ? 0 : 0.004 * fabs(v);      // bf16 output rounding
+            worst = std::max(worst, fabs(got - v) - tol);
+        }
+    hipFree(A); hipFree(W); hipFree(R); hipFree(bias); hipFree(ws); hipFree(C);
+    return worst;
+}
+static int check_all() {
+    int bad = 0;
+    struct Case { int M, N, K; bool resid, act; int bm; } cases[] = {
+        {512, 256, 128, false, false, 1}, {300, 384, 96, true, false, 1}, {777, 1500, 64, false, false, 2}, {256, 512, 512, true, true, 1}, {1000, 132, 32, false, true, 1}};
+    for (auto& c : cases) {
+        const double e1 = check_one<float, 128>(c.M, c.N, c.K, c.resid, c.act, c.bm), e2 = check_one<float, 256>(c.M, c.N, c.K, c.resid, c.act, c.bm);
+        const double e3 = check_one<bf16, 128>(c.M, c.N, c.K, c.resid, c.act, c.bm), e4 = check_one<bf16, 256>(c.M, c.N, c.K, c.resid, c.act, c.bm);
+        const bool ok = e1 < 2e-4 && e2 < 2e-4 && e3 < 2e-4 && e4 < 2e-4;
+        printf("check M%4d N%4d K%3d res%d act%d bias%d: excess error f32 %.1e %.1e  bf16 %.1e %.1e  %s\n", c.M, c.N, c.K, c.resid, c.act, c.bm, e1, e2, e3, e4, ok ? "ok" : "MISMATCH");
+        bad += !ok;
+    }
+    return bad;
+}
 int main() {
+    if (check_all()) return 1;
     const long M = 256L * 1500;
     struct Shape { const char* name; int N, K; bool f32out, resid, act; } shapes[] = {
         {"QK   N1024 K512 ", 1024, 512, false, false, false}, {"fc1  N2048 K512 gelu", 2048, 512, false, false, true},
