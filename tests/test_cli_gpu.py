@@ -188,3 +188,28 @@ def test_cli_batches_files_across_streams_and_reports_throughput(tmp_path):
     assert r1.returncode == 0, r1.stderr
     rows1 = json.loads((out1 / "p.json").read_text())
     assert [x["text"] for x in rows1] == [x["text"] for x in rows]
+
+
+def test_cli_finds_tokenizer_in_hf_cache(tmp_path):
+    """No --tokenizer-json, none in the model directories: the tokenizer.json of the newest snapshot of the model id's
+    Hugging Face cache entry is used (reference src/main.rs:597-633)."""
+    if wb.device_count() < 1:
+        pytest.fail("no MI355X visible")
+    hub = tmp_path / "hf" / "hub" / "models--acme--whisper-nano" / "snapshots"
+    tokj = json.dumps({"model": {"vocab": {}}, "added_tokens": [
+        {"id": 2, "content": "<|endoftext|>", "special": True}, {"id": 3, "content": "<|startoftranscript|>", "special": True},
+        {"id": 5, "content": "<|en|>", "special": True}, {"id": 7, "content": "<|transcribe|>", "special": True},
+        {"id": 9, "content": "<|notimestamps|>", "special": True}]})
+    for i, rev in enumerate(["aaa111", "bbb222", "ccc333"]):
+        (hub / rev).mkdir(parents=True)
+        if rev != "ccc333":                       # the newest directory holds no tokenizer: not a candidate
+            (hub / rev / "tokenizer.json").write_text(tokj)
+        os.utime(hub / rev, (1_700_000_000 + 1000 * i, 1_700_000_000 + 1000 * i))
+    out = tmp_path / "res"
+    env = dict(os.environ, HF_HOME=str(tmp_path / "hf"))
+    r = subprocess.run([CLI, "--onnx-dir", "synthetic:nano:7", "--model-id", "acme/whisper-nano", "--synthetic-clips", "2", "--max-new-tokens", "4",
+                        "--out-csv", str(out / "p.csv"), "--out-json", str(out / "p.json"), "--out-summary-json", str(out / "s.json")],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    s = json.loads((out / "s.json").read_text())
+    assert s["tokenizer_json"] == str(hub / "bbb222" / "tokenizer.json")

@@ -212,6 +212,35 @@ static std::vector<float> synthetic_clip(uint64_t seed) {
     return x;
 }
 
+// A model id of the form org/name that was downloaded earlier has its files under
+// $HF_HOME/hub/models--org--name/snapshots/<revision>/ ($HF_HOME defaults to $HOME/.cache/huggingface): the tokenizer.json of
+// the most recently modified snapshot directory that holds one (reference src/main.rs:597-633).  "" when there is none.
+static std::string hf_cache_tokenizer(const std::string& model_id) {
+    const size_t slash = model_id.find('/');
+    if (slash == std::string::npos || slash == 0 || slash + 1 >= model_id.size()) return "";
+    const std::string org = model_id.substr(0, slash), name = model_id.substr(slash + 1);
+    std::string base;
+    if (const char* h = getenv("HF_HOME")) base = h;
+    else { const char* home = getenv("HOME"); base = std::string(home ? home : ".") + "/.cache/huggingface"; }
+    const std::string snaps = base + "/hub/models--" + org + "--" + name + "/snapshots";
+    DIR* d = opendir(snaps.c_str());
+    if (!d) return "";
+    std::string best;
+    bool have = false;
+    struct timespec best_m = {0, 0};
+    while (struct dirent* e = readdir(d)) {
+        const std::string rev = e->d_name;
+        if (rev == "." || rev == "..") continue;
+        const std::string dir = snaps + "/" + rev, cand = dir + "/tokenizer.json";
+        struct stat st_dir, st_tok;
+        if (stat(cand.c_str(), &st_tok) != 0 || !S_ISREG(st_tok.st_mode) || stat(dir.c_str(), &st_dir) != 0) continue;
+        const bool newer = st_dir.st_mtim.tv_sec > best_m.tv_sec || (st_dir.st_mtim.tv_sec == best_m.tv_sec && st_dir.st_mtim.tv_nsec > best_m.tv_nsec);
+        if (!have || newer) { have = true; best_m = st_dir.st_mtim; best = cand; }
+    }
+    closedir(d);
+    return best;
+}
+
 static std::vector<int> parse_devices(const std::string& spec, int fallback) {   // "0-7", "0,2,5", "" -> {fallback}
     std::vector<int> out;
     if (trim(spec).empty()) { out.push_back(fallback); return out; }
@@ -284,13 +313,16 @@ int main(int argc, char** argv) {
         if (a.intra_op > 0) cfg.intra_op = a.intra_op;
         if (a.inter_op > 0) cfg.inter_op = a.inter_op;
 
-        Tokenizer tok;  // resolve_tokenizer, src/main.rs:574-635 (HF-cache scan not restated)
+        Tokenizer tok;  // resolve_tokenizer, src/main.rs:574-635: explicit path, model directories, then the Hugging Face cache
         if (!trim(a.tokenizer_json).empty()) {
             if (!is_file(trim(a.tokenizer_json))) throw std::runtime_error("tokenizer_json not found: " + trim(a.tokenizer_json));
             load_tokenizer(trim(a.tokenizer_json), tok);
         } else {
+            std::string found;
             for (const std::string& cand : {a.onnx_dir + "/tokenizer.json", a.model_id + "/tokenizer.json"})
-                if (is_file(cand)) { load_tokenizer(cand, tok); break; }
+                if (is_file(cand)) { found = cand; break; }
+            if (found.empty()) found = hf_cache_tokenizer(a.model_id);
+            if (!found.empty()) load_tokenizer(found, tok);
         }
         const bool synthetic_model = a.onnx_dir.rfind("synthetic:", 0) == 0;
         GenCfg gen = load_generation_cfg(a.onnx_dir + "/generation_config.json");
