@@ -256,6 +256,61 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
     }
 }
 
+// d % 512 == 0, 2-byte output: a lane owns 8 consecutive columns per 512-column sweep (two 16-byte loads, one 16-byte
+// store — 8-byte bf16 stores ran at 3 TB/s against 5 for 16-byte ones in the GEMM epilogue) and a wave carries two rows at
+// once, so four loads per lane are in flight instead of two.
+template <int SWEEPS>
+__global__ __launch_bounds__(256) void k_layernorm_w8(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ b, bf16* __restrict__ y, long rows, int d) {
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (row0 >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const bool two = row0 + 1 < rows;
+    const float* xr[2] = {x + row0 * d, x + (two ? row0 + 1 : row0) * d};
+    f32x4 v[2][SWEEPS][2];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int i = 0; i < SWEEPS; i++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) v[r][i][h] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr[r] + i * 512 + lane * 8 + h * 4));
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < SWEEPS; i++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) s += (v[r][i][h][0] + v[r][i][h][1]) + (v[r][i][h][2] + v[r][i][h][3]);
+        mean[r] = dpp_wave_sum(s) / (float)d;
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < SWEEPS; i++)
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const float t = v[r][i][h][e] - mean[r]; q += t * t; }
+        rstd[r] = rsqrtf(dpp_wave_sum(q) / (float)d + 1e-5f);
+    }
+#pragma unroll
+    for (int i = 0; i < SWEEPS; i++) {
+        const int c = i * 512 + lane * 8;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + c), w1 = *reinterpret_cast<const f32x4*>(w + c + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + c), b1 = *reinterpret_cast<const f32x4*>(b + c + 4);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            if (r == 1 && !two) break;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                o[e] = (bf16)((v[r][i][0][e] - mean[r]) * rstd[r] * w0[e] + b0[e]);
+                o[4 + e] = (bf16)((v[r][i][1][e] - mean[r]) * rstd[r] * w1[e] + b1[e]);
+            }
+            *reinterpret_cast<bf16x8*>(y + (row0 + r) * d + c) = o;
+        }
+    }
+}
+
 template <typename T, typename TO>
 void launch_gemm_t(hipStream_t s, const GemmArgs& g) {
     const long blocks128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch;
@@ -291,6 +346,12 @@ void wh_launch_gemm(hipStream_t s, int prec, bool out_f32, const GemmArgs& g) {
 void wh_launch_layernorm(hipStream_t s, int prec, const float* x, const float* w, const float* b, void* y, long rows,
                          int d) {
     dim3 grid((unsigned)((rows + 3) / 4));
+    if (prec != WH_PREC_F32 && (d == 512 || d == 1024) && getenv("WH_LN_W8_OFF") == nullptr) {
+        dim3 g8((unsigned)((rows + 7) / 8));
+        if (d == 512) hipLaunchKernelGGL(k_layernorm_w8<1>, g8, dim3(256), 0, s, x, w, b, (bf16*)y, rows, d);
+        else hipLaunchKernelGGL(k_layernorm_w8<2>, g8, dim3(256), 0, s, x, w, b, (bf16*)y, rows, d);
+        return;
+    }
     if (prec == WH_PREC_F32) hipLaunchKernelGGL(k_layernorm<float>, grid, dim3(256), 0, s, x, w, b, (float*)y, rows, d);
     else hipLaunchKernelGGL(k_layernorm<bf16>, grid, dim3(256), 0, s, x, w, b, (bf16*)y, rows, d);
 }
