@@ -23,8 +23,9 @@ template <typename TO, int BN, int ABL> float run(const GemmArgs& g, int reps) {
 }
 template <typename TO, int BN> void all(const char* name, const GemmArgs& g, double gf) {
     const float t0 = run<TO, BN, 0>(g, 5), t1 = run<TO, BN, 1>(g, 5), t4 = run<TO, BN, 4>(g, 5), t12 = run<TO, BN, 8 | 4>(g, 5), t16 = run<TO, BN, 16>(g, 5);
-    printf("%-26s BN %3d: full %7.1f us (%5.0f TF/s) | no-mfma %7.1f | no-epilogue %7.1f | loads+barriers only %7.1f | no-stores %7.1f\n", name, BN, t0,
-           gf / t0 * 1e3, t1, t4, t12, t16);
+    const float t36 = run<TO, BN, 32 | 4>(g, 5), t44 = run<TO, BN, 32 | 8 | 4>(g, 5);
+    printf("%-26s BN %3d: full %7.1f us (%5.0f TF/s) | no-mfma %7.1f | no-epilogue %7.1f | loads+barriers only %7.1f | no-stores %7.1f | no-epilogue, A stages only %7.1f | loads+barriers, A only %7.1f\n", name, BN, t0,
+           gf / t0 * 1e3, t1, t4, t12, t16, t36, t44);
 }
 // correctness first: every geometry / output type / tail against a host double-precision product
 template <typename TO, int BN> double check_one(int M, int N, int K, bool resid, bool act, int bias_mode) {

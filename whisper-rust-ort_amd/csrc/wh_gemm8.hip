@@ -75,7 +75,7 @@ __device__ __forceinline__ void store8(bf16* p, const f32x4& a, const f32x4& b) 
     *reinterpret_cast<bf16x8*>(p) = bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
 }
 
-// ABL (tools/gemm8_ablate.hip only; 0 in the library): 1 = no MFMA (fragment reads kept), 2 = no LDS-DMA inside the loop,
+// ABL (tools/gemm8_ablate.hip only; 0 in the library): 1 = no MFMA (fragment reads kept), 2 = no LDS-DMA inside the loop, 32 = no W stage,
 // 4 = no epilogue, 8 = no fragment reads and no MFMA (loads + barriers only), 16 = epilogue without its global stores
 template <typename TO, int BN, int ABL = 0>
 __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs g) {
@@ -123,6 +123,7 @@ __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs
         char* base = smem + slot * SLOT;
 #pragma unroll
         for (int j = 0; j < 2; j++) glds16(a_src[j] + (long)kt * BK, base + (wave * 32 + j * 16) * ROWB);
+        if (ABL & 32) return;   // (ablation: no W stage — what the loop would cost with the weight fragments coming from elsewhere)
 #pragma unroll
         for (int j = 0; j < G::W_INSTR; j++) glds16(w_src[j] + (long)kt * BK, base + SLOT_A + (wave * (16 * G::W_INSTR) + j * 16) * ROWB);
     };
@@ -164,9 +165,10 @@ __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs
     // vmcnt retires in issue order, so "at most newer * PER_STAGE outstanding" == "stage kt and everything older is done".
     auto wait_stage = [&](int kt, int cap) {
         const int newer = (ABL & 2) ? 0 : min(cap, nk - 1 - kt);
-        if (newer >= 3) wait_vm<3 * G::PER_STAGE>();
-        else if (newer == 2) wait_vm<2 * G::PER_STAGE>();
-        else if (newer == 1) wait_vm<G::PER_STAGE>();
+        constexpr int PS = (ABL & 32) ? 2 : G::PER_STAGE;
+        if (newer >= 3) wait_vm<3 * PS>();
+        else if (newer == 2) wait_vm<2 * PS>();
+        else if (newer == 1) wait_vm<PS>();
         else wait_vm<0>();
     };
     if (G::PIPE) {
