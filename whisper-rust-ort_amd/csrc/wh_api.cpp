@@ -110,6 +110,7 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
     {   // conv1 (k3,p1) + GELU: GEMM over overlapping rows of the token-major mel
         Prof p(c, WH_KG_ENC_GEMM);
         GemmArgs g;
+        g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
         g.A = c->melT; g.lda = C; g.a_bs = (long)TOK_ROWS * C; g.m_per = WH_N_FRAMES;
         g.W = m->conv1_w; g.ldw = m->conv1_k;
         g.C = (char*)c->h1 + d * esz; g.ldc = d; g.c_bs = (long)H1_ROWS * d;
@@ -120,6 +121,7 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
     {   // conv2 (k3,s2,p1) + GELU + sinusoid positions → f32 residual stream
         Prof p(c, WH_KG_ENC_GEMM);
         GemmArgs g;
+        g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
         g.A = c->h1; g.lda = 2 * d; g.a_bs = (long)H1_ROWS * d; g.m_per = (int)S;
         g.W = m->conv2_w; g.ldw = 3 * d;
         g.C = c->x; g.ldc = d; g.c_bs = S * d;
@@ -142,6 +144,8 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
         {   // Q|K projection (q pre-scaled, k has no bias)
             Prof p(c, WH_KG_ENC_GEMM);
             GemmArgs g;
+        g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
+            g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
             g.A = c->xn; g.lda = d; g.W = L.qk_w; g.ldw = d; g.C = c->qk; g.ldc = 2 * d;
             g.bias = L.qk_b; g.bias_mode = 1; g.wscale = L.qk_sc; g.M = (int)rows; g.N = (int)(2 * d); g.K = (int)d;
             if (mx) { g.A = c->xn8; g.a_sc = c->xn8_sc; g.W = L.qk_w8; wh_launch_gemm8_mx(s, 0, g); }
@@ -150,6 +154,8 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
         {   // V^T[e][key] = W_v x^T + b_v: per-clip product with the weight as the row operand
             Prof p(c, WH_KG_ENC_GEMM);
             GemmArgs g;
+        g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
+            g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
             g.A = L.v_w; g.lda = d; g.a_zs = 0;
             g.W = c->xn; g.ldw = d; g.w_zs = S * d;
             g.C = c->vT; g.ldc = c->ldv; g.c_zs = d * c->ldv;
@@ -165,6 +171,8 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
         {   // out-proj + bias + residual (in place on the f32 stream)
             Prof p(c, WH_KG_ENC_GEMM);
             GemmArgs g;
+        g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
+            g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
             g.A = c->att; g.lda = d; g.W = L.o_w; g.ldw = d; g.C = c->x; g.ldc = d;
             g.bias = L.o_b; g.bias_mode = 1; g.wscale = L.o_sc; g.R = c->x; g.ldr = d; g.M = (int)rows; g.N = (int)d; g.K = (int)d;
             wh_launch_gemm(s, prec, true, g);
@@ -177,6 +185,8 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
         {   // fc1 + GELU (MX: the output leaves as e4m3 codes + block exponents, fc2's operand)
             Prof p(c, WH_KG_ENC_GEMM);
             GemmArgs g;
+        g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
+            g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
             g.A = c->xn; g.lda = d; g.W = L.fc1_w; g.ldw = d; g.C = c->hbuf; g.ldc = F;
             g.bias = L.fc1_b; g.bias_mode = 1; g.wscale = L.fc1_sc; g.act = 1; g.M = (int)rows; g.N = (int)F; g.K = (int)d;
             if (mx) { g.A = c->xn8; g.a_sc = c->xn8_sc; g.W = L.fc1_w8; g.C = c->h8; g.c_sc = c->h8_sc; wh_launch_gemm8_mx(s, 2, g); }
@@ -185,6 +195,8 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
         {
             Prof p(c, WH_KG_ENC_GEMM);
             GemmArgs g;
+        g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
+            g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
             g.A = c->hbuf; g.lda = F; g.W = L.fc2_w; g.ldw = F; g.C = c->x; g.ldc = d;
             g.bias = L.fc2_b; g.bias_mode = 1; g.wscale = L.fc2_sc; g.R = c->x; g.ldr = d; g.M = (int)rows; g.N = (int)d; g.K = (int)F;
             if (mx) { g.A = c->h8; g.a_sc = c->h8_sc; g.W = L.fc2_w8; wh_launch_gemm8_mx(s, 1, g); }
@@ -287,6 +299,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     {
         Prof pr(c, WH_KG_DEC_GEMM);
         GemmArgs g;
+        g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
         g.A = c->enc_out; g.lda = d; g.W = m->cross_kv_w; g.ldw = d;
         g.C = c->cross_kv; g.ldc = d; g.n_per = (int)d; g.c_ns = kv_stride;
         g.bias = m->cross_kv_b; g.bias_mode = 1; g.wscale = m->cross_kv_sc;

@@ -331,7 +331,7 @@ void launch_gemm_t(hipStream_t s, const GemmArgs& g) {
 
 void wh_launch_gemm(hipStream_t s, int prec, bool out_f32, const GemmArgs& g) {
     static const bool use8 = getenv("WH_GEMM8") == nullptr || atoi(getenv("WH_GEMM8")) != 0;   // WH_GEMM8=0: A/B against k_gemm
-    if (prec != WH_PREC_F32 && use8 && wh_gemm8_applicable(g)) {
+    if (prec != WH_PREC_F32 && use8 && !g.small_ctx && wh_gemm8_applicable(g)) {
         wh_launch_gemm8(s, out_f32, g);
         return;
     }
