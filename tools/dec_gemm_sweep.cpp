@@ -1,6 +1,6 @@
 // dec_gemm_sweep.cpp — the six decode GEMM shapes of a layer at a given width and row count, weights cycling through a pool
 // larger than the caches, over the K split (4 / 8 waves), the rows per workgroup of k_dec_gemm and the column tiles per
-// workgroup of k_dec_gemm_wide.  Usage: dec_gemm_sweep <rows> <d_model> <ffn>
+// workgroup of k_dec_gemm_wide.  Usage: dec_gemm_sweep <rows> <d_model> <ffn> [matrices in the weight pool]
 // Build: hipcc --offload-arch=gfx950 -O2 -std=c++17 tools/dec_gemm_sweep.cpp -Lwhisper-rust-ort_amd -lwhisper_hip -Wl,-rpath,$PWD/whisper-rust-ort_amd -o tools/dec_gemm_sweep
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -26,7 +26,7 @@ static double time_chain(hipStream_t s, int reps, const std::function<void(int)>
 }
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 256, d = argc > 2 ? atoi(argv[2]) : 1280, F = argc > 3 ? atoi(argv[3]) : 5120;
-    const int MP = (B + 15) / 16 * 16, L = d >= 1024 ? 32 : 6;
+    const int MP = (B + 15) / 16 * 16, L = argc > 4 ? atoi(argv[4]) : (d >= 1024 ? 32 : 6);   // matrices in the pool (32 x 13 MB: HBM; 4: Infinity Cache; 1: L2)
     hipStream_t s; hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
     const size_t per_layer = (size_t)F * d * 2;
     char* pool = (char*)dmalloc(per_layer * L);
@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
     struct Case { const char* name; int N, K; bool ln, res; } cases[] = {
         {"LN+QKV", 3 * d, d, true, false}, {"o-proj +res+stats", d, d, false, true},
         {"LN+q", d, d, true, false}, {"LN+fc1", F, d, true, false}, {"fc2 +res+stats", d, F, false, true}};
-    printf("rows %d, d_model %d, ffn %d  (us per launch in a replayed chain, boundary included)\n", B, d, F);
+    printf("rows %d, d_model %d, ffn %d, pool of %d matrices  (us per launch in a replayed chain, boundary included)\n", B, d, F, L);
     for (auto& c : cases) {
         printf("%-18s N%5d K%5d :", c.name, c.N, c.K);
         double best = 1e9; char bestn[32] = "";
