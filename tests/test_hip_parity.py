@@ -506,3 +506,22 @@ def test_wide_batch_decode_gemm_is_bit_identical(gpu, monkeypatch, prec_name):
     for wide in ("-1", "2", "4"):
         assert res[wide][0] == res["0"][0], wide
         assert np.array_equal(res[wide][1], res["0"][1]), wide
+
+
+@pytest.mark.parametrize("prec_name", ["bf16", "fp8"])
+def test_largest_batch_rows_equal_small_calls_on_the_same_context(gpu, prec_name):
+    """One 1024-clip context: a full batch (wide decode GEMM tiles, one key range per clip, 64-row LM-head groups) against
+    the same clips submitted alone, in a batch of 3 and in a batch of 100 (k_dec_gemm, other row-group shapes) — a clip's
+    tokens never depend on what shares its batch."""
+    b = bundle("base", 1234, wb.PRECISIONS[prec_name], max_batch=1024)
+    prompt, eot = small_prompt(b.dims)
+    uniq = [ms.synth_clip(900 + i) for i in range(24)]
+    clips = [uniq[(i * 5) % 24] for i in range(1024)]
+    p = wb.DecodeParams(prompt, 48, eot, [eot])
+    full = [t.tolist() for t in b.ctx.transcribe_batch(clips, p)]
+    for i in range(24, 1024):                       # duplicates inside the batch
+        assert full[i] == full[i % 24], i
+    for i in (0, 7, 1023):
+        assert b.ctx.transcribe_batch([clips[i]], p)[0].tolist() == full[i]
+    assert [t.tolist() for t in b.ctx.transcribe_batch(clips[5:8], p)] == full[5:8]
+    assert [t.tolist() for t in b.ctx.transcribe_batch(clips[300:400], p)] == full[300:400]
