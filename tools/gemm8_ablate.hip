@@ -27,6 +27,72 @@ template <typename TO, int BN> void all(const char* name, const GemmArgs& g, dou
     printf("%-26s BN %3d: full %7.1f us (%5.0f TF/s) | no-mfma %7.1f | no-epilogue %7.1f | loads+barriers only %7.1f | no-stores %7.1f | no-epilogue, A stages only %7.1f | loads+barriers, A only %7.1f\n", name, BN, t0,
            gf / t0 * 1e3, t1, t4, t12, t16, t36, t44);
 }
+// The global -> LDS stream alone, two ways: MODE 0 = LDS-DMA as in k_gemm8 (global_load_lds_dwordx4, counted vmcnt waits, one barrier
+// per k-step); MODE 1 = register-staged (global_load_dwordx4 into VGPRs, ds_write_b128 one k-step before the data is due).  Same
+// tiles, same slot ring (256 x 256 x 32, four 32 KiB slots, three stages in flight), same source swizzle; nothing reads the slots.
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void k_stream_skeleton(GemmArgs g, unsigned* sink) {
+    constexpr int BN = 256, NSLOT = 4, SLOT_A = BM * ROWB, SLOT = SLOT_A + BN * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = g.K / BK, nbn = (g.N + BN - 1) / BN, total = nbn * ((g.M + BM - 1) / BM);
+    int tile = blockIdx.x;
+    { const int q = total >> 3, r = total & 7, xcd = tile & 7, idx = tile >> 3; tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; }
+    const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
+    const int rl = lane >> 2, ps = lane & 3;
+    const bf16* src[4];
+    int dst[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int row = wave * 32 + (j & 1) * 16 + rl;
+        const bool isw = j >= 2;
+        const long r = min(isw ? n0 + row : m0 + row, (isw ? g.N : g.M) - 1);
+        src[j] = (const bf16*)(isw ? g.W : g.A) + r * (isw ? g.ldw : g.lda) + ((ps ^ swz(row)) << 3);
+        dst[j] = (isw ? SLOT_A : 0) + (wave * 32 + (j & 1) * 16) * ROWB;     // wave-instruction base; lane i lands at + i * 16
+    }
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    u4 regs[NSLOT - 1][4];
+    auto issue = [&](int kt, int set) {      // set = kt % 3, passed as a compile-time constant of the unrolled callers
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (MODE == 0) glds16(src[j] + (long)kt * BK, smem + (kt % NSLOT) * SLOT + dst[j]);
+            else regs[set][j] = *reinterpret_cast<const u4*>(src[j] + (long)kt * BK);
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < NSLOT - 1; t++) if (t < nk) issue(t, t);
+    for (int kt = 0; kt < nk; kt += 3) {            // three k-steps per iteration: the register sets are named statically
+#pragma unroll
+        for (int h = 0; h < 3; h++) {
+            const int t = kt + h;
+            if (t >= nk) break;
+            const int newer = min(NSLOT - 2, nk - 1 - t);
+            if (newer >= 2) wait_vm<8>(); else if (newer == 1) wait_vm<4>(); else wait_vm<0>();
+            if (MODE == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) *reinterpret_cast<u4*>(smem + (t % NSLOT) * SLOT + dst[j] + lane * 16) = regs[h][j];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (t + NSLOT - 1 < nk) issue(t + NSLOT - 1, h);
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+    if (sink && tid == 0 && blockIdx.x == 0) *sink = reinterpret_cast<unsigned*>(smem)[lane];
+}
+template <int MODE> float run_skeleton(const GemmArgs& g, int reps) {
+    const size_t sm = (size_t)4 * (BM + 256) * ROWB;
+    (void)hipFuncSetAttribute((const void*)k_stream_skeleton<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    dim3 grid(((g.N + 255) / 256) * ((g.M + BM - 1) / BM));
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    hipLaunchKernelGGL((k_stream_skeleton<MODE>), grid, dim3(512), sm, 0, g, (unsigned*)nullptr);
+    (void)hipEventRecord(a, 0);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL((k_stream_skeleton<MODE>), grid, dim3(512), sm, 0, g, (unsigned*)nullptr);
+    (void)hipEventRecord(b, 0); (void)hipEventSynchronize(b);
+    float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
+    return ms / reps * 1e3f;
+}
+
 // correctness first: every geometry / output type / tail against a host double-precision product
 template <typename TO, int BN> double check_one(int M, int N, int K, bool resid, bool act, int bias_mode) {
     std::vector<unsigned short> ha((size_t)M * K), hw((size_t)N * K);
@@ -99,6 +165,7 @@ int main() {
         g.act = sh.act; g.M = (int)M; g.N = sh.N; g.K = sh.K;
         if (sh.resid) { g.R = R; g.ldr = sh.N; }
         const double gf = 2.0 * M * sh.N * sh.K * 1e-9;
+        printf("%-26s global -> LDS stream alone, 256 x 256 tiles: LDS-DMA %7.1f us | register-staged %7.1f us\n", sh.name, run_skeleton<0>(g, 5), run_skeleton<1>(g, 5));
         if (sh.f32out) { all<float, 128>(sh.name, g, gf); all<float, 256>(sh.name, g, gf); }
         else { all<bf16, 128>(sh.name, g, gf); all<bf16, 256>(sh.name, g, gf); }
     }
