@@ -36,10 +36,10 @@ __device__ __forceinline__ void pack_p(bf16x8& f, const f32x4& a, const f32x4& b
 }
 __device__ __forceinline__ void pack_p(f32x8& f, const f32x4& a, const f32x4& b) { f = f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, const T* __restrict__ vT,
-                                                  T* __restrict__ out, int S, int d, int ldv, int n_heads) {
-    constexpr int HD = WH_HEAD_DIM, KV = 64, QB = 128;
+template <typename T, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void k_enc_attn(const T* __restrict__ qk, const T* __restrict__ vT,
+                                                          T* __restrict__ out, int S, int d, int ldv, int n_heads) {
+    constexpr int HD = WH_HEAD_DIM, KV = 64, QB = NWAVES * 32, NT_ = NWAVES * 64;
     constexpr int LD = HD + 16 / (int)sizeof(T);  // padded LDS row of the K tile (elements): +16 B, conflict-free for 16-B reads
     // V^T tile: read 8 bytes per lane (bf16), 16 lanes per LDS cycle — rows 144 B apart put lanes fl and fl+8 on the
     // same banks (2-way conflict on every read); 136-B rows spread the 16 lanes over all 32 banks.  Its staging
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, cons
     constexpr int LDV = sizeof(T) == 2 ? HD + 4 : LD;
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int CPR = HD / EPC;                 // 16-B chunks per 64-element row
-    constexpr int NCH = KV * CPR / 256;           // staging chunks per thread per operand: 2 (bf16) / 4 (f32)
+    constexpr int NCH = KV * CPR / NT_;           // staging chunks per thread per operand: 2 (bf16) / 4 (f32) with 4 waves, half with 8
     typedef typename FragT<T>::type frag_t;
     typedef typename HalfFrag<T>::type half_t;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, cons
     int st_row[NCH], st_col[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; i++) {
-        const int c = tid + i * 256;
+        const int c = tid + i * NT_;
         st_row[i] = c / CPR;
         st_col[i] = (c % CPR) * EPC;
     }
@@ -170,9 +170,14 @@ __global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, cons
                     for (int r = 0; r < 4; r++)
                         if (k0 + t * 16 + 4 * fg + r >= S) sc[u][t][r] = -INFINITY;
             }
-            float mx = fmaxf(fmaxf(sc[u][0][0], sc[u][0][1]), fmaxf(sc[u][0][2], sc[u][0][3]));
+            // a chain of max(max(m, a), b): one v_max3_f32 per two scores (16 per query column instead of the 24 a balanced tree takes)
+            float mx = fmaxf(sc[u][0][0], sc[u][0][1]);
+            mx = fmaxf(fmaxf(mx, sc[u][0][2]), sc[u][0][3]);
 #pragma unroll
-            for (int t = 1; t < 4; t++) mx = fmaxf(mx, fmaxf(fmaxf(sc[u][t][0], sc[u][t][1]), fmaxf(sc[u][t][2], sc[u][t][3])));
+            for (int t = 1; t < 4; t++) {
+                mx = fmaxf(fmaxf(mx, sc[u][t][0]), sc[u][t][1]);
+                mx = fmaxf(fmaxf(mx, sc[u][t][2]), sc[u][t][3]);
+            }
             mx = xrow_max(mx);
             const float mn = fmaxf(mrow[u], mx);
             const float alpha = __builtin_amdgcn_exp2f((mrow[u] - mn) * LOG2E);
@@ -235,13 +240,22 @@ __global__ __launch_bounds__(256) void k_enc_attn(const T* __restrict__ qk, cons
 
 void wh_launch_enc_attn(hipStream_t s, int prec, const void* qk, const void* vT, void* out, int n_clips, int S, int d,
                         int n_heads, int ldv) {
-    dim3 grid(((S + 127) / 128) * n_heads * n_clips);
     if (prec == WH_PREC_F32) {
+        dim3 grid(((S + 127) / 128) * n_heads * n_clips);
         const size_t sm = (size_t)2 * 2 * 64 * (64 + 4) * 4;  // 69.6 KB: above the default dynamic-LDS limit
-        wh_ensure_dyn_lds((const void*)k_enc_attn<float>, sm);
-        hipLaunchKernelGGL(k_enc_attn<float>, grid, dim3(256), sm, s, (const float*)qk, (const float*)vT, (float*)out, S, d, ldv, n_heads);
+        wh_ensure_dyn_lds((const void*)k_enc_attn<float, 4>, sm);
+        hipLaunchKernelGGL((k_enc_attn<float, 4>), grid, dim3(256), sm, s, (const float*)qk, (const float*)vT, (float*)out, S, d, ldv, n_heads);
     } else {
         const size_t sm = (size_t)2 * 2 * 64 * (64 + 8) * 2;
-        hipLaunchKernelGGL(k_enc_attn<bf16>, grid, dim3(256), sm, s, (const bf16*)qk, (const bf16*)vT, (bf16*)out, S, d, ldv, n_heads);
+        // 8 waves = 256 query rows per workgroup: each K / V^T tile is staged once per 256 queries instead of once per 128
+        // (a per-query result does not depend on the grouping).  WH_ENC_ATTN_W4=1: the 4-wave form, for A/B runs.
+        static const bool w4 = getenv("WH_ENC_ATTN_W4") != nullptr && atoi(getenv("WH_ENC_ATTN_W4")) != 0;
+        if (w4) {
+            dim3 grid(((S + 127) / 128) * n_heads * n_clips);
+            hipLaunchKernelGGL((k_enc_attn<bf16, 4>), grid, dim3(256), sm, s, (const bf16*)qk, (const bf16*)vT, (bf16*)out, S, d, ldv, n_heads);
+        } else {
+            dim3 grid(((S + 255) / 256) * n_heads * n_clips);
+            hipLaunchKernelGGL((k_enc_attn<bf16, 8>), grid, dim3(512), sm, s, (const bf16*)qk, (const bf16*)vT, (bf16*)out, S, d, ldv, n_heads);
+        }
     }
 }
