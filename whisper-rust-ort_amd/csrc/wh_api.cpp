@@ -144,7 +144,6 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
         {   // Q|K projection (q pre-scaled, k has no bias)
             Prof p(c, WH_KG_ENC_GEMM);
             GemmArgs g;
-        g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
             g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
             g.A = c->xn; g.lda = d; g.W = L.qk_w; g.ldw = d; g.C = c->qk; g.ldc = 2 * d;
             g.bias = L.qk_b; g.bias_mode = 1; g.wscale = L.qk_sc; g.M = (int)rows; g.N = (int)(2 * d); g.K = (int)d;
@@ -154,7 +153,6 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
         {   // V^T[e][key] = W_v x^T + b_v: per-clip product with the weight as the row operand
             Prof p(c, WH_KG_ENC_GEMM);
             GemmArgs g;
-        g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
             g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
             g.A = L.v_w; g.lda = d; g.a_zs = 0;
             g.W = c->xn; g.ldw = d; g.w_zs = S * d;
@@ -171,7 +169,6 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
         {   // out-proj + bias + residual (in place on the f32 stream)
             Prof p(c, WH_KG_ENC_GEMM);
             GemmArgs g;
-        g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
             g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
             g.A = c->att; g.lda = d; g.W = L.o_w; g.ldw = d; g.C = c->x; g.ldc = d;
             g.bias = L.o_b; g.bias_mode = 1; g.wscale = L.o_sc; g.R = c->x; g.ldr = d; g.M = (int)rows; g.N = (int)d; g.K = (int)d;
@@ -185,7 +182,6 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
         {   // fc1 + GELU (MX: the output leaves as e4m3 codes + block exponents, fc2's operand)
             Prof p(c, WH_KG_ENC_GEMM);
             GemmArgs g;
-        g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
             g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
             g.A = c->xn; g.lda = d; g.W = L.fc1_w; g.ldw = d; g.C = c->hbuf; g.ldc = F;
             g.bias = L.fc1_b; g.bias_mode = 1; g.wscale = L.fc1_sc; g.act = 1; g.M = (int)rows; g.N = (int)F; g.K = (int)d;
@@ -195,7 +191,6 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
         {
             Prof p(c, WH_KG_ENC_GEMM);
             GemmArgs g;
-        g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
             g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
             g.A = c->hbuf; g.lda = F; g.W = L.fc2_w; g.ldw = F; g.C = c->x; g.ldc = d;
             g.bias = L.fc2_b; g.bias_mode = 1; g.wscale = L.fc2_sc; g.R = c->x; g.ldr = d; g.M = (int)rows; g.N = (int)d; g.K = (int)F;
