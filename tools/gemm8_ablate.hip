@@ -82,8 +82,9 @@ __global__ __launch_bounds__(512, 2) void k_stream_skeleton(GemmArgs g, unsigned
 }
 // The same stream with 128-byte LDS rows (64 k per stage, 8 whole rows per wave-instruction: every request a full cache line):
 // 256 x 128 tiles, three 48 KiB slots, two stages in flight (96 KB, as above).  Reports bytes moved so the rates compare.
+template <int BN, int NSLOT>
 __global__ __launch_bounds__(512, 2) void k_stream_skeleton128(GemmArgs g, unsigned* sink) {
-    constexpr int BN = 128, BK2 = 64, ROWB2 = 128, NSLOT = 3, SLOT_A = BM * ROWB2, SLOT = SLOT_A + BN * ROWB2;
+    constexpr int BK2 = 64, ROWB2 = 128, SLOT_A = BM * ROWB2, SLOT = SLOT_A + BN * ROWB2, WI = BN / 64, NI = 4 + WI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = g.K / BK2, nbn = (g.N + BN - 1) / BN, total = nbn * ((g.M + BM - 1) / BM);
@@ -91,39 +92,39 @@ __global__ __launch_bounds__(512, 2) void k_stream_skeleton128(GemmArgs g, unsig
     { const int q = total >> 3, r = total & 7, xcd = tile & 7, idx = tile >> 3; tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; }
     const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
     const int rl = lane >> 3, ps = lane & 7;
-    const bf16* src[6];
-    int dst[6];
+    const bf16* src[NI];
+    int dst[NI];
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
+    for (int j = 0; j < NI; j++) {
         const bool isw = j >= 4;
-        const int row = isw ? wave * 16 + (j - 4) * 8 + rl : wave * 32 + j * 8 + rl;
+        const int row = isw ? wave * (8 * WI) + (j - 4) * 8 + rl : wave * 32 + j * 8 + rl;
         const long r = min(isw ? n0 + row : m0 + row, (isw ? g.N : g.M) - 1);
         src[j] = (const bf16*)(isw ? g.W : g.A) + r * (isw ? g.ldw : g.lda) + ((ps ^ ((row >> 1) & 7)) << 3);
-        dst[j] = (isw ? SLOT_A : 0) + (isw ? wave * 16 + (j - 4) * 8 : wave * 32 + j * 8) * ROWB2;
+        dst[j] = (isw ? SLOT_A : 0) + (isw ? wave * (8 * WI) + (j - 4) * 8 : wave * 32 + j * 8) * ROWB2;
     }
     auto issue = [&](int kt) {
 #pragma unroll
-        for (int j = 0; j < 6; j++) glds16(src[j] + (long)kt * BK2, smem + (kt % NSLOT) * SLOT + dst[j]);
+        for (int j = 0; j < NI; j++) glds16(src[j] + (long)kt * BK2, smem + (kt % NSLOT) * SLOT + dst[j]);
     };
 #pragma unroll
     for (int t = 0; t < NSLOT - 1; t++) if (t < nk) issue(t);
     for (int t = 0; t < nk; t++) {
         const int newer = min(NSLOT - 2, nk - 1 - t);
-        if (newer >= 1) wait_vm<6>(); else wait_vm<0>();
+        if (newer >= 1) wait_vm<NI>(); else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         if (t + NSLOT - 1 < nk) issue(t + NSLOT - 1);
     }
     __builtin_amdgcn_s_barrier();
     if (sink && tid == 0 && blockIdx.x == 0) *sink = reinterpret_cast<unsigned*>(smem)[lane];
 }
-static float run_skeleton128(const GemmArgs& g, int reps) {
-    const size_t sm = (size_t)3 * (BM + 128) * 128;
-    (void)hipFuncSetAttribute((const void*)k_stream_skeleton128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    dim3 grid(((g.N + 127) / 128) * ((g.M + BM - 1) / BM));
+template <int BN, int NSLOT> static float run_skeleton128(const GemmArgs& g, int reps) {
+    const size_t sm = (size_t)NSLOT * (BM + BN) * 128;
+    (void)hipFuncSetAttribute((const void*)k_stream_skeleton128<BN, NSLOT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    dim3 grid(((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM));
     hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-    hipLaunchKernelGGL(k_stream_skeleton128, grid, dim3(512), sm, 0, g, (unsigned*)nullptr);
+    hipLaunchKernelGGL((k_stream_skeleton128<BN, NSLOT>), grid, dim3(512), sm, 0, g, (unsigned*)nullptr);
     (void)hipEventRecord(a, 0);
-    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_stream_skeleton128, grid, dim3(512), sm, 0, g, (unsigned*)nullptr);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL((k_stream_skeleton128<BN, NSLOT>), grid, dim3(512), sm, 0, g, (unsigned*)nullptr);
     (void)hipEventRecord(b, 0); (void)hipEventSynchronize(b);
     float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
     return ms / reps * 1e3f;
@@ -214,10 +215,10 @@ int main() {
         if (sh.resid) { g.R = R; g.ldr = sh.N; }
         const double gf = 2.0 * M * sh.N * sh.K * 1e-9;
         {
-            const float t0 = run_skeleton<0>(g, 5), t1 = run_skeleton<1>(g, 5), t2 = run_skeleton128(g, 5);
+            const float t0 = run_skeleton<0>(g, 5), t1 = run_skeleton<1>(g, 5), t2 = run_skeleton128<128, 3>(g, 5), t3 = run_skeleton128<256, 2>(g, 5);
             const double b256 = (double)((M + 255) / 256) * ((sh.N + 255) / 256) * (sh.K / 32) * 32768.0, b128 = (double)((M + 255) / 256) * ((sh.N + 127) / 128) * (sh.K / 64) * 49152.0;
-            printf("%-26s global -> LDS stream alone: 256 x 256 tiles, 64-byte rows: LDS-DMA %7.1f us (%5.2f TB/s) | register-staged %7.1f us | 256 x 128 tiles, 128-byte rows: LDS-DMA %7.1f us (%5.2f TB/s)\n",
-                   sh.name, t0, b256 / t0 * 1e-6, t1, t2, b128 / t2 * 1e-6);
+            printf("%-26s global -> LDS stream alone: 256 x 256 tiles, 64-byte rows, 3 x 32 KB in flight: LDS-DMA %7.1f us (%5.2f TB/s) | register-staged %7.1f us | 128-byte rows: 256 x 128 tiles, 2 x 48 KB in flight %7.1f us (%5.2f TB/s); 256 x 256 tiles, 1 x 64 KB in flight %7.1f us (%5.2f TB/s)\n",
+                   sh.name, t0, b256 / t0 * 1e-6, t1, t2, b128 / t2 * 1e-6, t3, b256 / t3 * 1e-6);
         }
         if (sh.f32out) { all<float, 128>(sh.name, g, gf); all<float, 256>(sh.name, g, gf); }
         else { all<bf16, 128>(sh.name, g, gf); all<bf16, 256>(sh.name, g, gf); }
