@@ -2,7 +2,8 @@
 """bench.py — headline benchmark of the MI355X-native Whisper hot path.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: plain `python bench.py --gpus N` starts one rank per GPU itself; under
+     `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` it joins the ranks it is given)
 
 Workload (BASELINE.json configs[2] scaled to the GPUs present; at N=1 it is configs[1]'s model
 and dtype on one GPU's share of the clip set): whisper-base dims, bf16 MFMA, hash-seeded synthetic
@@ -33,36 +34,16 @@ if ROOT not in sys.path:
 from whisper_rust_ort_amd import binding as wb  # noqa: E402
 from whisper_rust_ort_amd import modelspec as ms  # noqa: E402
 
+# chip partition defaults (profiles/r03_cu_partition_sweep.txt); --pipeline / --enc-cus override
+DEFAULT_PIPELINE = 0
+DEFAULT_ENC_CUS = 64
+
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA
 MFMA_F32_PEAK_TF = 157.3
 
 
-class Hip:
-    """Just enough of the HIP runtime (the instance libwhisper_hip.so already loaded) to keep the
-    benchmark's PCM resident in HBM."""
-
-    def __init__(self):
-        self.lib = C.CDLL("libamdhip64.so.7", mode=C.RTLD_GLOBAL)
-        self.lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-        self.lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        self.lib.hipFree.argtypes = [C.c_void_p]
-        self.lib.hipSetDevice.argtypes = [C.c_int]
-
-    def check(self, rc, what):
-        if rc != 0:
-            raise RuntimeError(f"{what} failed with hipError {rc}")
-
-    def upload(self, dev: int, arr: np.ndarray) -> int:
-        self.check(self.lib.hipSetDevice(dev), "hipSetDevice")
-        p = C.c_void_p()
-        self.check(self.lib.hipMalloc(C.byref(p), arr.nbytes), "hipMalloc")
-        self.check(self.lib.hipMemcpy(p, arr.ctypes.data_as(C.c_void_p), arr.nbytes, 1), "hipMemcpy H2D")
-        self.check(self.lib.hipDeviceSynchronize(), "hipDeviceSynchronize")
-        return p.value
-
-    def sync(self):
-        self.check(self.lib.hipDeviceSynchronize(), "hipDeviceSynchronize")
+Hip = wb.HipRuntime   # device-resident PCM (hipMalloc / hipMemcpy of the runtime the library already loaded)
 
 
 def algorithmic_work(dims, n_clips: int, n_prompt: int, max_new: int, kv_esz: int) -> dict:
@@ -84,24 +65,49 @@ def algorithmic_work(dims, n_clips: int, n_prompt: int, max_new: int, kv_esz: in
     }
 
 
-def cpu_baseline(dims, seed: int, prompt, eot, max_new: int) -> dict:
-    """The oracle (a port of the reference's algorithm — the Rust/ORT binary cannot be built here)
-    timed on this box's host cores for ONE clip of the same workload."""
+def cpu_baseline(dims, seed: int, prompt, eot, max_new: int, levels=None) -> dict:
+    """The oracle (a port of the reference's algorithm — the Rust/ORT binary cannot be built here) timed on this box's
+    host cores in the reference's benchmarked shape: clip-parallel, ONE thread per clip
+    (`--chunk-parallelism N --intra-op 1`, run_benchmark_without_hf_pipeline_rust.sh:7-9; src/main.rs:884-919), at
+    N = 4, 8 and all usable cores; each level transcribes N clips of the same workload concurrently, once."""
+    import threading
     from oracle import oracle as orc
     w = ms.flatten_state_dict(dims, ms.synth_state_dict(dims, seed))
-    pcm = ms.synth_clip(0)
-    t0 = time.perf_counter()
-    mel = orc.log_mel(pcm, dims.n_mels)
-    t1 = time.perf_counter()
-    enc = orc.encoder(dims, w, mel)
-    t2 = time.perf_counter()
-    toks, _ = orc.decode_greedy(dims, w, enc, prompt, max_new, eot, suppress=[eot])
-    t3 = time.perf_counter()
-    return {"value": 30.0 / (t3 - t0), "unit": "x real time (audio s / wall s)", "cores": orc.num_threads(),
-            "kind": "port",
-            "sample": f"1 clip (30 s), whisper-base fp32, {max_new} new tokens, OpenMP C oracle; "
-                      f"mel {t1 - t0:.3f}s enc {t2 - t1:.3f}s dec {t3 - t2:.3f}s",
-            "seconds": t3 - t0, "tokens": [int(t) for t in toks[:8]]}
+    cores = orc.cpu_budget()
+    L = orc.lib()
+    if levels is None:
+        levels = sorted({min(4, cores), min(8, cores), cores})
+
+    def one(i, out):
+        L.orc_set_threads(1)   # OpenMP's team size is per calling thread: every clip runs on exactly one core
+        pcm = ms.synth_clip(i)
+        t0 = time.perf_counter()
+        mel = orc.log_mel(pcm, dims.n_mels)
+        t1 = time.perf_counter()
+        enc = orc.encoder(dims, w, mel)
+        t2 = time.perf_counter()
+        toks, _ = orc.decode_greedy(dims, w, enc, prompt, max_new, eot, suppress=[eot])
+        out[i] = (t1 - t0, t2 - t1, time.perf_counter() - t2, [int(t) for t in toks[:8]])
+
+    sweep = []
+    for n in levels:
+        out = {}
+        th = [threading.Thread(target=one, args=(i, out)) for i in range(n)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        el = time.perf_counter() - t0
+        per = np.asarray([v[0] + v[1] + v[2] for v in out.values()])
+        sweep.append({"clips_in_parallel": n, "threads": n, "seconds": el, "rtfx": 30.0 * n / el,
+                      "p95_s_per_clip": float(np.percentile(per, 95)),
+                      "mel_enc_dec_s_clip0": [round(x, 3) for x in out[0][:3]]})
+    best = max(sweep, key=lambda r: r["rtfx"])
+    return {"value": best["rtfx"], "unit": "x real time (audio s / wall s)", "cores": best["threads"], "kind": "port",
+            "sample": f"{best['clips_in_parallel']} clips (30 s each) transcribed concurrently, one thread per clip, whisper-base fp32, "
+                      f"{max_new} new tokens, C oracle; {best['seconds']:.1f} s wall",
+            "seconds": best["seconds"], "clip_parallel_sweep": sweep, "tokens": out[0][3]}
 
 
 def self_launch(n: int) -> int:
@@ -158,10 +164,20 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--clips", type=int, default=1024,
-                    help="clips per GPU per step (one device batch resident in HBM; 1024 = the library's largest batch, "
-                         "≈50 GB of workspace + caches at whisper-base size; rounds 1-2 quoted 256, kept as the `batch256` side figure)")
+    ap.add_argument("--clips", type=int, default=0,
+                    help="clips per GPU per step (one device batch resident in HBM); default: the largest batch the preset's "
+                         "workspace allows — 1024 for whisper-base (≈50 GB of workspace + caches), 256 for whisper-large-v3 (≈99 GB)")
+    ap.add_argument("--total-clips", type=int, default=0,
+                    help="strong scaling (BASELINE configs[2]/[4]: '512 clips sharded over N GPUs'): the whole job's clips per step, "
+                         "dealt evenly to the ranks; overrides --clips and reports \"scaling\": \"strong\"")
     ap.add_argument("--streams", type=int, default=1, help="independent HIP streams (contexts) per GPU; clips are split evenly")
+    ap.add_argument("--pipeline", type=int, default=None, choices=[0, 1],
+                    help="1: chip partition — step i runs log-mel + encoder of step i+1's batch on the encoder stream (its own compute "
+                         "units) beside step i's token loop (wh_transcribe_batch_device_next); 0: one stream, one phase at a time")
+    ap.add_argument("--enc-cus", type=int, default=-1,
+                    help="compute units of the encoder stream in pipeline mode (multiple of 8: the same count from every XCD); "
+                         "0 = no CU masks, two plain streams; default: the measured best (profiles/r03_cu_partition_sweep.txt)")
+    ap.add_argument("--dec-cus", type=int, default=-1, help="compute units of the token-loop stream (default: the other 256 - enc-cus)")
     ap.add_argument("--preset", default="base")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "fp8"])
     ap.add_argument("--max-new-tokens", type=int, default=128)
@@ -177,6 +193,7 @@ def main() -> None:
     ap.add_argument("--launch-check", action="store_true",
                     help="no GPU work: every rank joins a gloo group, gathers one dummy record and rank 0 prints what it saw "
                          "(CPU test of the launcher and the rendezvous)")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="launcher test: with --launch-check, this rank exits with status 3 before the rendezvous")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -191,7 +208,16 @@ def main() -> None:
     if world != a.gpus:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {a.gpus}: launch one rank per GPU "
                          f"(python bench.py --gpus N starts them itself)")
+    scaling = "weak"
+    if a.total_clips:   # strong scaling: the job's clip set is fixed and dealt evenly to the ranks (src/main.rs:884-919 deals a fixed window set to its workers)
+        if a.total_clips % world:
+            raise SystemExit(f"--total-clips {a.total_clips} is not a multiple of the {world} ranks")
+        a.clips = a.total_clips // world
+        scaling = "strong"
     if a.launch_check:
+        if a.fail_rank == rank:
+            print(f"[bench] rank {rank}: --fail-rank asked this rank to die before the rendezvous", file=sys.stderr)
+            raise SystemExit(3)
         import torch.distributed as dist
         from whisper_rust_ort_amd import sharding
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -201,7 +227,7 @@ def main() -> None:
         rec = sharding.gather_records(dist, sharding.pack_records(ids, [np.array([rank, local_rank])] * 2, 4))
         tmax = sharding.max_over_ranks(dist, float(rank))
         if rank == 0:
-            print(json.dumps({"launch_check": True, "world": world, "max_rank": tmax,
+            print(json.dumps({"launch_check": True, "world": world, "max_rank": tmax, "scaling": scaling, "clips_per_gpu": a.clips,
                               "records": [[c, t.tolist()] for c, t in sharding.unpack_records(rec)]}), flush=True)
         dist.barrier()
         dist.destroy_process_group()
@@ -235,19 +261,45 @@ def main() -> None:
     esz = 4 if prec == wb.WH_PREC_F32 else 2
     if wb.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: libwhisper_hip has no CPU fallback")
+    if a.clips <= 0:   # the largest device batch whose workspace + caches fit comfortably
+        a.clips = {"base": 1024, "large-v3": 256}.get(a.preset, 256)
+        if prec == wb.WH_PREC_F32 and a.preset in ("base", "large-v3"):
+            a.clips //= 4
+    if a.pipeline is None:
+        a.pipeline = DEFAULT_PIPELINE if a.streams == 1 else 0
+    if a.pipeline and a.streams != 1:
+        raise SystemExit("--pipeline 1 overlaps the phases of ONE context; use it with --streams 1")
+    if a.enc_cus < 0:
+        a.enc_cus = DEFAULT_ENC_CUS
+    if a.dec_cus < 0:
+        a.dec_cus = wb.N_CUS - a.enc_cus if a.enc_cus else 0
     dev = local_rank
     model = wb.Model(f"synthetic:{a.preset}:{a.seed}", dev, prec)
     assert a.clips % a.streams == 0, "--clips must be a multiple of --streams"
     per_stream = a.clips // a.streams
-    ctxs = [wb.Context(model, per_stream) for _ in range(a.streams)]
+    if a.pipeline:
+        # encoder stream on the low mask bits, token loop on the bits above them (disjoint unless --dec-cus says otherwise)
+        em = wb.cu_mask(0, a.enc_cus) if a.enc_cus else None
+        dm = wb.cu_mask(wb.N_CUS - a.dec_cus, a.dec_cus) if a.dec_cus else None
+        ctxs = [wb.Context(model, per_stream, enc_cu_mask=em, dec_cu_mask=dm, two_streams=True)]
+    else:
+        ctxs = [wb.Context(model, per_stream) for _ in range(a.streams)]
     ctx = ctxs[0]
     hip = Hip()
 
-    # this rank's shard of the clip set: clip ids rank*clips .. (rank+1)*clips-1 (weak scaling)
+    # this rank's shard of the clip set: clip ids rank*clips .. (rank+1)*clips-1 (weak scaling: per-GPU work is fixed;
+    # --total-clips: the job's clip set is fixed and dealt to the ranks).  Pipeline mode alternates between two such
+    # batches (the second one: the same ids + 1,000,000) so that a step's prefetched encoder pass reads other clips
+    # than the batch being decoded.
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as gen:   # numpy releases the GIL in the bulk of it
-        pcm = np.stack(list(gen.map(lambda i: ms.synth_clip(rank * a.clips + i), range(a.clips))))
-    d_pcm = hip.upload(dev, pcm)
+    n_bufs = 2 if a.pipeline else 1
+    d_bufs = []
+    for k in range(n_bufs):
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as gen:   # numpy releases the GIL in the bulk of it
+            pcm = np.stack(list(gen.map(lambda i: ms.synth_clip(1000000 * k + rank * a.clips + i), range(a.clips))))
+        d_bufs.append(hip.upload(dev, pcm))
+        del pcm
+    d_pcm = d_bufs[0]
     if dims.vocab > 50400:
         prompt, eot = [50258, 50259, 50359, 50363], 50257  # reference src/main.rs:549-566
     else:
@@ -261,9 +313,18 @@ def main() -> None:
 
     pool = ThreadPoolExecutor(max_workers=a.streams)
 
-    def run_step():
+    step_no = [0]
+
+    def run_step(prefetch: bool = True):
         """One pass over this GPU's clips: every stream transcribes its slice concurrently (ctypes
-        releases the GIL; each context owns a HIP stream)."""
+        releases the GIL; each context owns a HIP stream).  Pipeline mode: one context; the call also puts log-mel +
+        encoder of the NEXT step's batch on the encoder stream, where they run beside this step's token loop — every
+        step therefore executes one full encoder pass and one full decode pass, nothing is cached or skipped."""
+        if a.pipeline:
+            k = step_no[0]
+            step_no[0] += 1
+            cur, nxt = d_bufs[k % 2], d_bufs[(k + 1) % 2]
+            return ctx.transcribe_batch_device(cur, a.clips, params, next_ptr=nxt if prefetch else None, next_n=a.clips)
         def one(i):
             return ctxs[i].transcribe_batch_device(d_pcm + i * per_stream * 480000 * 4, per_stream, params)
         if a.streams == 1:
@@ -274,11 +335,31 @@ def main() -> None:
     # untimed: warmup + one fully profiled pass to find the dominant kernel group
     toks = None
     for _ in range(max(1, a.warmup)):
-        toks = run_step()
+        toks = run_step(prefetch=False)
     assert all(len(t) == len(prompt) + a.max_new_tokens for t in toks), "EOT suppressed: every clip decodes max_new tokens"
+    # parity of the timed entry (wh_transcribe_batch_device*, a full device batch) with a one-clip call on the same
+    # context: rows 0 and 3 must be identical — a clip decodes the same alone or in a batch
+    row_check = None
+    if rank == 0:
+        step_no[0] = 0
+        full = run_step(prefetch=False)                 # batch 0 again, unpipelined
+        for r in (0, min(3, a.clips - 1)):
+            alone = ctx.transcribe_batch_device(d_bufs[0] + r * 480000 * 4, 1, params)[0]
+            assert alone.tolist() == full[r].tolist(), f"row {r} of the device batch differs from the one-clip call"
+        if a.pipeline:                                  # and the pipelined call returns what the plain call returns
+            step_no[0] = 0
+            piped = run_step(prefetch=True)
+            piped2 = run_step(prefetch=False)           # consumes the prefetched encoder states of batch 1
+            step_no[0] = 1
+            plain2 = run_step(prefetch=False)           # batch 1 from scratch
+            assert [t.tolist() for t in piped] == [t.tolist() for t in full], "pipelined call differs from the plain call"
+            assert [t.tolist() for t in piped2] == [t.tolist() for t in plain2], "prefetched encoder states differ from recomputed ones"
+        row_check = "rows 0 and 3 of the device batch == one-clip calls on the same context" + (
+            "; pipelined == plain call on both batches" if a.pipeline else "")
+    step_no[0] = 0
     for cx in ctxs:
         cx.profile_enable(True)
-    run_step()
+    run_step(prefetch=False)
     breakdown = {k: {"ms": sum(cx.profile_get()[k]["ms"] for cx in ctxs) / a.streams,
                      "launches": sum(cx.profile_get()[k]["launches"] for cx in ctxs)} for k in wb.KG_NAMES}
     # BASELINE configs[1] (batch = 1 clip on one GPU): per-clip end-to-end latency, untimed extra
@@ -330,12 +411,24 @@ def main() -> None:
     # timed region: EXACTLY K steps
     lat = []
     stage = {"preprocess_s": 0.0, "encode_s": 0.0, "decode_s": 0.0}
+    step_no[0] = 0
+    if a.pipeline:
+        # steady state: the last untimed step prefetches the first timed step's encoder pass, and EVERY timed step
+        # (the last one too) runs the next batch's encoder pass beside its token loop — K encoder passes and K decode
+        # passes execute inside the timed region; the closing barrier waits for the last encoder pass as well
+        step_no[0] = 1
+        run_step(prefetch=True)      # decodes batch 1, prefetches batch 0
+        step_no[0] = 0
     barrier()
     t0 = time.perf_counter()
+    t_prev = t0
     for _ in range(a.steps):
         ts = time.perf_counter()
         toks = run_step()   # returns after the last D2H of the step
-        lat.append(time.perf_counter() - ts)
+        # per-clip latency: every clip of a batch completes with its batch; in pipeline mode a batch's encoder pass
+        # was enqueued at the start of the PREVIOUS step, so its clips have been in flight since then
+        lat.append(time.perf_counter() - (t_prev if a.pipeline else ts))
+        t_prev = ts
         for cx in ctxs:
             tm = cx.timings()
             for k in stage:
@@ -371,6 +464,7 @@ def main() -> None:
         avg_s = live["ms"] * 1e-3 / max(1, live["launches"])
         ach = work["cross_attn_bytes_per_launch"] / avg_s / 1e9
         traffic = None
+        traffic_stamp = None
         # the dominant kernel's variants: e4m3 cache (fp8 mode), one workgroup per 256-column group (wide models), all heads per workgroup
         dom_kernel = ("k_dec_cross_attn8" if prec == wb.WH_PREC_FP8 else
                       "k_dec_cross_attn_cg" if (prec == wb.WH_PREC_BF16 and dims.d_model > 512 and dims.d_model % 256 == 0) else "k_dec_cross_attn")
@@ -379,8 +473,11 @@ def main() -> None:
             tj = json.load(open(tpath))
             key = f"{a.preset}_{a.precision}_b{per_stream}"
             traffic = tj.get(dom_kernel, {}).get(key)
+            traffic_stamp = tj.get("_collected_at", {}).get(key)
         roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": traffic, "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/pmc_traffic.json (profiles/collect.sh)",
+                    "traffic": traffic, "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/pmc_traffic.json (profiles/collect.sh); "
+                                                          "NOT measured in this run — counters of the build named in traffic_collected_at",
+                    "traffic_collected_at": traffic_stamp,
                     "kernel": dom_kernel, "avg_launch_us": avg_s * 1e6,
                     "launches_timed": live["launches"], "alg_bytes_per_launch": work["cross_attn_bytes_per_launch"],
                     "share_of_kernel_time": breakdown["dec_cross_attn"]["ms"] / tot_ms}
@@ -406,24 +503,32 @@ def main() -> None:
         # reads 0.91-0.98 at 1.9-2.0 GHz, profiles/r02_mfma_util_calibration.txt)
         upath = os.path.join(ROOT, "profiles", "mfma_util.json")
         if os.path.exists(upath):
-            uj = json.load(open(upath)).get(f"{a.preset}_{a.precision}_b{per_stream}", {})
+            ujall = json.load(open(upath))
+            ukey = f"{a.preset}_{a.precision}_b{per_stream}"
+            uj = ujall.get(ukey, {})
+            ustamp = ujall.get("_collected_at", {}).get(ukey)
             def grp(prefixes):
-                ks = [k for k in uj if k.startswith(prefixes)]
+                ks = [k for k in uj if k.startswith(prefixes) and uj[k].get("shader_clock_GHz")]
                 busy = sum(uj[k]["mfma_util"] * uj[k]["total_ms_under_pmc"] * uj[k]["shader_clock_GHz"] for k in ks)
                 cyc = sum(uj[k]["total_ms_under_pmc"] * uj[k]["shader_clock_GHz"] for k in ks)
-                return {"mfma_util": busy / cyc, "kernels": {k: uj[k]["mfma_util"] for k in ks}} if cyc > 0 else None
+                return {"mfma_util": busy / cyc, "kernels": {k: uj[k]["mfma_util"] for k in ks},
+                        "collected_at": ustamp, "note": "counter pass of the build named in collected_at, not of this run"} if cyc > 0 else None
             secondary["enc_attn"]["rocprof"] = grp(("k_enc_attn",))
             secondary["enc_gemm"]["rocprof"] = grp(("k_gemm8", "k_gemm<"))
         out = {
             "metric": f"rtfx: audio seconds transcribed per wall second (whisper-{a.preset}, 30 s clips, greedy {a.max_new_tokens} new tokens)",
             "value": audio_s / elapsed, "unit": "x real time", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": a.precision, "data": "synthetic",
             "config": {"workload": f"whisper-{a.preset} dims, hash-seeded weights, {a.clips} synthetic 30 s clips per GPU per step "
                                    f"(BASELINE configs[2]'s clip generator and decode settings, model/dtype of configs[1]; one device batch "
                                    f"per step), greedy, max_new_tokens={a.max_new_tokens}, EOT suppressed, PCM resident in HBM",
                        "clips_per_gpu": a.clips, "streams_per_gpu": a.streams, "parallelism": f"clip-sharded x{world}",
-                       "gather": backend, "results_gathered": n_results},
+                       "total_clips_per_step": a.clips * world,
+                       "pipeline": ({"enc_cus": a.enc_cus or "all", "dec_cus": a.dec_cus or "all",
+                                     "note": "step i's token loop and step i+1's log-mel + encoder run side by side on disjoint compute units; "
+                                             "every timed step executes one encoder pass and one decode pass"} if a.pipeline else None),
+                       "gather": backend, "results_gathered": n_results, "row_check": row_check},
             "rtf": elapsed / audio_s,   # reference definition: latency / duration (src/main.rs:1191)
             "clips_per_s": a.clips * a.steps * world / elapsed,
             "p95_ms_per_clip": float(np.percentile(np.asarray(lat) * 1e3, 95)),  # every clip of a batch completes with its batch

@@ -50,11 +50,15 @@ extern "C" {
 /* arithmetic type of the Linear/conv/attention contractions */
 #define WH_PREC_F32 0  /* exact-f32 MFMA (v_mfma_f32_16x16x4_f32): the token-for-token / 1e-3-logit mode */
 #define WH_PREC_BF16 1 /* bf16 MFMA, f32 accumulate, f32 residual stream: the throughput mode */
-#define WH_PREC_FP8 2  /* BASELINE configs[4]: Linear/QKV weights as OCP e4m3 codes with one f32 scale per output channel
-                          (dequantised in registers, bf16 MFMA, f32 accumulate and scale), cross-attention K/V cache as
-                          e4m3 with one scale per (clip, layer, K|V, head); convolutions, LayerNorms, biases, embeddings
-                          and all activations as in WH_PREC_BF16.  Reference analogue: weights-only QInt8 on
-                          MatMul/Gemm, quantize_onnx_int8.py:37-42 */
+#define WH_PREC_FP8 2  /* BASELINE configs[4]: Linear/QKV weights as OCP e4m3 codes with one f32 scale per output channel;
+                          cross-attention K/V cache as e4m3 with one scale per (clip, layer, K|V, head).  Encoder GEMMs
+                          fed by a LayerNorm or by the GELU output (Q|K, V^T, fc1, fc2, cross-K/V projection) run on the
+                          fp8 matrix cores (v_mfma_scale_f32_16x16x128_f8f6f4) with MX-quantised activations — e4m3 codes
+                          + one power-of-two exponent per (row, 32 columns) — wherever the model's widths allow
+                          (DESIGN.md §4a); decoder GEMMs dequantise the codes in registers into the bf16 MFMA operand.
+                          Convolutions, LayerNorm parameters, biases, embeddings (so the tied LM head) and the remaining
+                          activations as in WH_PREC_BF16.  Reference analogue: ORT dynamic quantisation of MatMul/Gemm
+                          (int8 weights, per-call quantised activations), quantize_onnx_int8.py:37-42 */
 
 #define WH_N_FRAMES 3000      /* mel frames per 30 s window (src/main.rs:896) */
 #define WH_CLIP_SAMPLES 480000 /* 30 s @ 16 kHz */
@@ -120,6 +124,23 @@ int wh_model_export_tensor(const wh_model* m, const char* name, float* out, size
 /* ---- per-stream context: workspace + KV cache for up to max_batch clips in flight ------------- */
 #define WH_MAX_BATCH 1024   /* largest max_batch wh_ctx_create accepts */
 int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out);
+/* Chip partition (no reference counterpart; the reference overlaps windows on CPU threads, src/main.rs:884-919).
+ * A context created with these options runs log-mel + encoder on one HIP stream and the cross-K/V projection + token
+ * loop on another, each optionally confined to a set of compute units (hipExtStreamCreateWithCUMask), so that
+ * wh_transcribe_batch_device_next can run the NEXT batch's MFMA-bound encoder beside this batch's HBM-bound token loop.
+ * A CU mask is `words` 32-bit words; on MI355X bit i selects compute unit i / 8 of XCD i % 8 (256 bits), so the low n
+ * bits are n compute units spread evenly over the 8 XCDs.  words == 0: the stream may use the whole chip. */
+#define WH_CTX_TWO_STREAMS 1 /* separate encoder / decode streams even without CU masks */
+typedef struct {
+    size_t struct_size;          /* sizeof(wh_ctx_opts): guards against a caller built for another layout */
+    int max_batch;               /* as wh_ctx_create */
+    int flags;                   /* WH_CTX_* */
+    const uint32_t* enc_cu_mask; /* log-mel + encoder stream */
+    size_t enc_cu_mask_words;
+    const uint32_t* dec_cu_mask; /* cross-K/V projection + token loop stream */
+    size_t dec_cu_mask_words;
+} wh_ctx_opts;
+int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out);
 void wh_ctx_free(wh_ctx* c);
 const char* wh_last_error(const wh_ctx* c); /* c == NULL: last load/create error of this thread */
 int wh_get_timings(const wh_ctx* c, wh_timing* out);
@@ -162,6 +183,16 @@ int wh_transcribe_batch(wh_ctx* c, const wh_clip* clips, size_t n_clips, const w
  * device (each clip exactly 30 s).  This is the entry bench.py times (inputs resident in HBM). */
 int wh_transcribe_batch_device(wh_ctx* c, const float* d_pcm, size_t n_clips, const wh_decode_params* p,
                                int64_t* tokens_out, size_t* n_tokens_out);
+/* Software-pipelined form of the same call (the reference's analogue is its window pool, src/main.rs:884-919: while one
+ * window decodes, other threads already run the encoder of the next ones).  Transcribes the batch at d_pcm exactly like
+ * wh_transcribe_batch_device and, if d_pcm_next != NULL, puts log-mel + encoder of the batch at d_pcm_next on the ctx's
+ * encoder stream as soon as this batch's cross-K/V projection has been enqueued: they run beside this batch's token loop.
+ * A following call whose (d_pcm, n_clips) equal that (d_pcm_next, n_clips_next) finds its encoder states resident and
+ * starts with the cross-K/V projection; any other call simply recomputes them.  Results are identical to the
+ * unpipelined call (same kernels, same order per clip).  d_pcm_next must stay valid and unchanged until that call. */
+int wh_transcribe_batch_device_next(wh_ctx* c, const float* d_pcm, size_t n_clips, const float* d_pcm_next,
+                                    size_t n_clips_next, const wh_decode_params* p, int64_t* tokens_out,
+                                    size_t* n_tokens_out);
 
 /* ---- long-form (src/main.rs:834-1008): whole-file mel once, 30 s windows every
  * (chunk_len - overlap) samples, all windows decoded as batches; returns per-window tokens ------ */

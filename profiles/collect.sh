@@ -11,6 +11,7 @@ mkdir -p "$OUT"
 R=$GRAFT_REPO_ROOT
 cd /tmp; export TMPDIR=/tmp
 export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
+export WH_COLLECT_STAMP="${WH_COLLECT_STAMP:-$(cat $R/profiles/.stamp 2>/dev/null || echo unstamped)}"
 ARGS="$R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch1 --graph-timed --precision $PREC --clips $CLIPS --preset $PRESET"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ARGS > "$OUT/trace.log" 2>&1
 python3 $R/profiles/summarize_kernel_stats.py "$(ls $OUT/trace/*/*kernel_stats.csv | head -1)" 4 > "$OUT/kernel_stats.txt"

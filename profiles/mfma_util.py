@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """MFMA utilisation per kernel from a `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` pass.
 
-    python3 mfma_util.py <counter_collection.csv> <out.csv> [skip-dispatches-per-kernel]
+    python3 mfma_util.py <counter_collection.csv> <out.csv> [skip-dispatches-per-kernel [<mfma_util.json> <config-key>]]
+
+The clock column (and with it the utilisation) is only meaningful for launches of >= 1 ms: GRBM_GUI_ACTIVE of a
+microsecond-scale launch includes the dispatch ramp on both sides of the kernel's own timestamps, so the derived clock
+reads 4-13 "GHz" and the utilisation is understated.  Such rows are printed with `clock n/a` and carry
+"short_launch": true in the JSON.
 
 Calibration on gfx950 (tools/mfma_util_calib.hip, profiles/r02_mfma_util_calibration.txt): SQ_VALU_MFMA_BUSY_CYCLES comes summed
 over every SIMD of the chip and counts 16 cycles per v_mfma_f32_16x16x32_bf16 (the instruction's issue time); GRBM_GUI_ACTIVE comes
@@ -75,15 +80,28 @@ def main():
         t = sum(dur[k][i] for i in ids)
         if gui <= 0:
             continue
-        rows.append((k, len(ids), t * 1e3, busy, gui, busy / (gui / 8.0 * 1024.0), gui / 8.0 / t / 1e9 if t > 0 else 0.0))
+        short = t / max(1, len(ids)) < 1e-3     # average launch below 1 ms: clock (and utilisation) not meaningful
+        rows.append((k, len(ids), t * 1e3, busy, gui, busy / (gui / 8.0 * 1024.0), gui / 8.0 / t / 1e9 if t > 0 else 0.0, short))
     rows.sort(key=lambda r: -r[2])
     with open(dst, "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "launches", "total_ms_under_pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "mfma_util", "shader_clock_GHz"])
         for r in rows:
-            w.writerow([r[0], r[1], f"{r[2]:.3f}", f"{r[3]:.0f}", f"{r[4]:.0f}", f"{r[5]:.4f}", f"{r[6]:.3f}"])
+            w.writerow([r[0], r[1], f"{r[2]:.3f}", f"{r[3]:.0f}", f"{r[4]:.0f}", f"{r[5]:.4f}", "n/a (launch < 1 ms)" if r[7] else f"{r[6]:.3f}"])
     for r in rows[:20]:
-        print(f"{r[0][:64]:64s} {r[1]:6d} launches {r[2]:10.2f} ms  MFMA util {r[5]:.3f}  clock {r[6]:.2f} GHz")
+        clock = "clock n/a (launch < 1 ms: utilisation understated)" if r[7] else f"clock {r[6]:.2f} GHz"
+        print(f"{r[0][:64]:64s} {r[1]:6d} launches {r[2]:10.2f} ms  MFMA util {r[5]:.3f}  {clock}")
+    if len(sys.argv) > 5:
+        import json
+        import os
+        try:
+            uj = json.load(open(sys.argv[4]))
+        except Exception:
+            uj = {}
+        uj[sys.argv[5]] = {r[0]: {"launches": r[1], "total_ms_under_pmc": round(r[2], 3), "mfma_util": round(r[5], 4),
+                                  "shader_clock_GHz": None if r[7] else round(r[6], 3), "short_launch": r[7]} for r in rows}
+        uj.setdefault("_collected_at", {})[sys.argv[5]] = os.environ.get("WH_COLLECT_STAMP", "unstamped")
+        json.dump(uj, open(sys.argv[4], "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

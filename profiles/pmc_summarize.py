@@ -58,6 +58,8 @@ def main():
             tj = {}
         for r in rows:
             tj.setdefault(r[0], {})[sys.argv[5]] = r[6]
+        import os
+        tj.setdefault("_collected_at", {})[sys.argv[5]] = os.environ.get("WH_COLLECT_STAMP", "unstamped")   # build the counters describe
         json.dump(tj, open(sys.argv[4], "w"), indent=1, sort_keys=True)
 
 

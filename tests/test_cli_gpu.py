@@ -46,8 +46,11 @@ def test_cli_end_to_end_matches_oracle_tokens(tmp_path):
         "encoder_layers": dims.enc_layers, "decoder_layers": dims.dec_layers, "encoder_ffn_dim": dims.ffn, "decoder_ffn_dim": dims.ffn,
         "vocab_size": dims.vocab, "max_source_positions": 1500, "max_target_positions": 448}))
     (mdir / "generation_config.json").write_text(json.dumps({"suppress_tokens": [432, 182], "begin_suppress_tokens": [1]}))
-    # tokenizer.json so prompt ids resolve inside the nano vocabulary
-    (mdir / "tokenizer.json").write_text(json.dumps({"model": {"vocab": {}}, "added_tokens": [
+    # tokenizer.json so prompt ids resolve inside the nano vocabulary; every ordinary id i detokenises to " t<i>"
+    # (byte-level BPE: "Ġ" is the space byte), so the CLI's text spells out exactly which ids the GPU path produced
+    special_ids = {2, 3, 5, 7, 9}
+    vocab = {f"\u0120t{i}": i for i in range(dims.vocab) if i not in special_ids}
+    (mdir / "tokenizer.json").write_text(json.dumps({"model": {"vocab": vocab}, "added_tokens": [
         {"id": 2, "content": "<|endoftext|>", "special": True}, {"id": 3, "content": "<|startoftranscript|>", "special": True},
         {"id": 5, "content": "<|en|>", "special": True}, {"id": 7, "content": "<|transcribe|>", "special": True},
         {"id": 9, "content": "<|notimestamps|>", "special": True}]}))
@@ -64,9 +67,16 @@ def test_cli_end_to_end_matches_oracle_tokens(tmp_path):
     rows = json.loads((out / "p.json").read_text())
     assert [x["file"] for x in rows] == ["a_long.wav", "b_short.wav"]            # sorted (src/main.rs:1122)
     w = ms.flatten_state_dict(dims, sd)
+    import ctypes as C
+    H = C.CDLL(os.path.join(ROOT, "whisper-rust-ort_amd", "libwh_host.so"))
+    H.whh_stitch.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    H.whh_stitch.restype = C.c_size_t
     for row in rows:
         x = pcm[row["file"]]
         assert row["duration_s"] == round(len(x) / 16000.0, 3)
+        # the oracle's tokens per window (whole-file mel, window cut, prompt stripped, trailing EOT stripped: :926-934),
+        # detokenised by the rule above and stitched like the reference stitches window texts (:659-696, tested on its own
+        # in test_host_cpu.py) — the CLI's long-form + stitch path on the GPU must print exactly that
         mel_full = orc.log_mel(x, 80)
         texts = []
         for off in wb.longform_plan(len(x)):
@@ -75,8 +85,14 @@ def test_cli_end_to_end_matches_oracle_tokens(tmp_path):
             gen = toks[4:].tolist()
             if gen and gen[-1] == 2:
                 gen.pop()
-            texts.append("")  # every id is outside the (empty) vocab → decodes to "" → "[EMPTY]" is dropped (:936-942)
-        assert row["text"] == ""
+            assert gen and not (set(gen) & special_ids)
+            texts.append("".join(f" t{t}" for t in gen))   # what decode_tokens yields for the window
+        blob = b"".join(t.encode() + b"\0" for t in texts)
+        buf = C.create_string_buffer(4096)
+        H.whh_stitch(blob, len(texts), buf, 4096)
+        want = buf.value.decode()
+        assert len(want.split()) >= 6
+        assert row["text"] == want, (row["file"], row["text"], want)
     s = json.loads((out / "s.json").read_text())
     txt = (out / "s.json").read_text()
     assert list(s.keys()) == sorted(s.keys())                                    # serde_json map order
@@ -86,7 +102,7 @@ def test_cli_end_to_end_matches_oracle_tokens(tmp_path):
     assert txt.startswith('{\n  "breakdown_s": {\n    "decode_s": {\n      "max": ')
     csv = (out / "p.csv").read_text().splitlines()
     assert csv[0] == "file,duration_s,end_to_end_s,rtf,text" and csv[1].startswith("a_long.wav,45.625,")
-    assert (out / "a_long.transcript.txt").read_text() == "\n"
+    assert (out / "a_long.transcript.txt").read_text() == rows[0]["text"] + "\n"
 
 
 def test_cli_token_fallback_text_matches_library(tmp_path):

@@ -525,3 +525,75 @@ def test_largest_batch_rows_equal_small_calls_on_the_same_context(gpu, prec_name
         assert b.ctx.transcribe_batch([clips[i]], p)[0].tolist() == full[i]
     assert [t.tolist() for t in b.ctx.transcribe_batch(clips[5:8], p)] == full[5:8]
     assert [t.tolist() for t in b.ctx.transcribe_batch(clips[300:400], p)] == full[300:400]
+
+
+# ------------------------------------------------------------------------------------------------
+# the entry bench.py times (PCM resident in HBM) and its pipelined form
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("preset,seed,prec_name,nb", [("micro", 11, "f32", 6), ("base", 1234, "bf16", 64), ("base", 1234, "bf16", 1024)])
+def test_device_entry_equals_host_entry(gpu, preset, seed, prec_name, nb):
+    """wh_transcribe_batch_device (device-resident [n][480000] f32, every clip exactly 30 s — what bench.py times) returns
+    exactly what wh_transcribe_batch returns for the same clips from host memory, and the f32 case is held to the oracle.
+    Covers the device entry's own code: no H2D, the constant sample / frame counts, the caller's PCM pointer."""
+    b = bundle(preset, seed, wb.PRECISIONS[prec_name], max_batch=nb)
+    prompt, eot = small_prompt(b.dims)
+    uniq = [ms.synth_clip(1200 + i) for i in range(min(nb, 16))]
+    clips = [uniq[(i * 7) % len(uniq)] for i in range(nb)]
+    p = wb.DecodeParams(prompt, 12, eot, [eot])
+    host = [t.tolist() for t in b.ctx.transcribe_batch(clips, p)]
+    hip = wb.HipRuntime()
+    d_pcm = hip.upload(0, np.stack(clips))
+    try:
+        dev = [t.tolist() for t in b.ctx.transcribe_batch_device(d_pcm, nb, p)]
+        assert dev == host
+        # a sub-batch starting in the middle of the device array
+        k = nb // 2
+        assert [t.tolist() for t in b.ctx.transcribe_batch_device(d_pcm + k * 480000 * 4, nb - k, p)] == host[k:]
+    finally:
+        hip.free(d_pcm)
+    if prec_name == "f32":
+        for i in (0, nb - 1):
+            mel = orc.window_mel(orc.log_mel(clips[i], b.dims.n_mels), 0, 3000)
+            ref, _ = orc.decode_greedy(b.dims, b.w, orc.encoder(b.dims, b.w, mel), prompt, 12, eot, [eot])
+            assert host[i] == ref.tolist(), i
+
+
+@pytest.mark.parametrize("masks", ["two_streams", "cu_masks"])
+def test_pipelined_device_entry_equals_plain(gpu, masks):
+    """wh_transcribe_batch_device_next on a two-stream context (with and without CU masks): batch A with B's encoder pass
+    prefetched beside A's token loop, then B from the prefetched states, then A again without a prefetch — identical to the
+    one-stream context's results for A and B; a call for another batch than the prefetched one recomputes; stage timings
+    stay positive."""
+    b = bundle("base", 1234, wb.WH_PREC_BF16, max_batch=64)
+    prompt, eot = small_prompt(b.dims)
+    p = wb.DecodeParams(prompt, 24, eot, [eot])
+    A = [ms.synth_clip(1300 + i) for i in range(64)]
+    B = [ms.synth_clip(1400 + i) for i in range(48)]
+    ref_a = [t.tolist() for t in b.ctx.transcribe_batch(A, p)]
+    ref_b = [t.tolist() for t in b.ctx.transcribe_batch(B, p)]
+    if masks == "cu_masks":
+        ctx = wb.Context(b.model, 64, enc_cu_mask=wb.cu_mask(0, 64), dec_cu_mask=wb.cu_mask(64, 192))
+    else:
+        ctx = wb.Context(b.model, 64, two_streams=True)
+    hip = wb.HipRuntime()
+    da, db = hip.upload(0, np.stack(A)), hip.upload(0, np.stack(B))
+    try:
+        got_a = [t.tolist() for t in ctx.transcribe_batch_device(da, 64, p, next_ptr=db, next_n=48)]
+        got_b = [t.tolist() for t in ctx.transcribe_batch_device(db, 48, p, next_ptr=da, next_n=64)]   # prefetched; prefetches A
+        tm = ctx.timings()
+        got_a2 = [t.tolist() for t in ctx.transcribe_batch_device(da, 64, p)]                         # prefetched, no further prefetch
+        assert got_a == ref_a and got_b == ref_b and got_a2 == ref_a
+        assert tm["preprocess_s"] > 0 and tm["encode_s"] > 0 and tm["decode_s"] > 0
+        # prefetch B, then ask for A's second half instead: the prefetched states are not used, the result is A's
+        ctx.transcribe_batch_device(da, 64, p, next_ptr=db, next_n=48)
+        assert [t.tolist() for t in ctx.transcribe_batch_device(da + 32 * 480000 * 4, 32, p)] == ref_a[32:]
+        # the staged API and the host entry still work on a two-stream context
+        assert [t.tolist() for t in ctx.transcribe_batch(B, p)] == ref_b
+        mel = ctx.whisper_log_mel(A[0])
+        ctx.run_encoder(mel)
+        one, _ = ctx.greedy_decode_with_past(p)
+        assert one.tolist() == ref_a[0]
+    finally:
+        ctx.close()
+        hip.free(da)
+        hip.free(db)

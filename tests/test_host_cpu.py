@@ -7,6 +7,7 @@ import math
 import os
 import struct
 import subprocess
+import sys
 import wave
 
 import numpy as np
@@ -251,3 +252,59 @@ def test_results_table_from_summaries(tmp_path):
     rt.main(["--summary", f"GPU run={tmp_path / 'mi355x_bf16' / 'inference_summary.json'}", "--out-md", str(md), "--out-csv", str(cs),
              "--extra-columns"])
     assert "| GPU run | bf16 | 1 | 0s | n/a | 512 | 27000.0 |" in md.read_text()
+
+
+# ------------------------------------------------------------------------------------------------
+# the CLI's loader / worker pipeline (wh_host.h run_file_pipeline): order, batching rules, fail-fast without deadlock
+# ------------------------------------------------------------------------------------------------
+def _pipeline(nfiles, loaders, workers, max_batch, bad_load, bad_process, pool_buffers, long_every, timeout=60):
+    """Runs whh_pipeline_selftest in a child process so that a deadlock shows up as a timeout instead of hanging pytest."""
+    code = f"""
+import ctypes as C, sys
+L = C.CDLL({os.path.join(PKG, 'libwh_host.so')!r})
+L.whh_pipeline_selftest.argtypes = [C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+                                    C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+n = C.c_size_t(0)
+err = C.create_string_buffer(512)
+rc = L.whh_pipeline_selftest({nfiles}, {loaders}, {workers}, {max_batch}, {bad_load}, {bad_process}, {pool_buffers}, {long_every}, C.byref(n), err, 512)
+print(rc, n.value, err.value.decode())
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr
+    rc, n, *msg = r.stdout.strip().split(" ", 2)
+    return int(rc), int(n), (msg[0] if msg else "")
+
+
+def test_pipeline_processes_every_file_once_in_order():
+    NONE = 10 ** 9
+    for loaders, workers, mb, long_every, pool in [(1, 1, 1, 0, 0), (4, 2, 8, 0, 10 ** 6), (8, 3, 4, 7, 10 ** 6), (3, 1, 16, 2, 0)]:
+        rc, n, msg = _pipeline(300, loaders, workers, mb, NONE, NONE, pool, long_every)
+        assert (rc, n) == (0, 300), (loaders, workers, mb, long_every, msg)
+
+
+def test_pipeline_fails_fast_on_a_bad_file_among_more_than_the_look_ahead():
+    """One undecodable file among many more files than the look-ahead (cap = 2 * max_batch * workers + 4): the loaders
+    that are parked waiting for queue space and the ones waiting for a staging buffer must all wake up and leave; the
+    reference fails with the loader's message (src/main.rs:1174-1176 propagates the first Err)."""
+    NONE = 10 ** 9
+    for bad in (0, 1, 57, 299):
+        for loaders, workers, mb in [(8, 1, 1), (8, 2, 4), (2, 3, 16)]:
+            rc, n, msg = _pipeline(300, loaders, workers, mb, bad, NONE, 10 ** 6, 0)
+            assert rc == 1 and msg == f"cannot decode file {bad}", (bad, loaders, workers, mb, rc, msg)
+            assert n < 300
+
+
+def test_pipeline_fails_fast_when_a_worker_fails():
+    NONE = 10 ** 9
+    for bad in (0, 33, 299):
+        rc, n, msg = _pipeline(300, 6, 2, 4, NONE, bad, 10 ** 6, 5)
+        assert rc == 1 and msg == f"transcribe failed for file {bad}", (bad, rc, msg)
+
+
+def test_pipeline_runs_without_the_pool_when_page_locked_memory_runs_out():
+    """The allocator runs dry before the pool is complete: all-or-nothing, so the run falls back to pageable buffers instead
+    of leaving the loader of the next index waiting for a buffer that parked later indices hold."""
+    NONE = 10 ** 9
+    for avail in (1, 5, 23):
+        rc, n, msg = _pipeline(200, 8, 2, 4, NONE, NONE, avail, 0)
+        assert (rc, n) == (0, 200), (avail, msg)

@@ -73,6 +73,81 @@ def test_large_v3_f32_against_oracle():
     np.testing.assert_allclose(lg, lr, rtol=0, atol=2e-3)
 
 
+def _teacher_forced_vs_golden(ctx, g, rows, label, err_bound):
+    """Teacher-forced decode of the resident batch on the golden token history `forced_c`: logit error of every golden row
+    against the f32 golden top-k values, and argmax agreement on the steps whose f32 top-1 margin exceeds twice the
+    measured error (the pattern of test_bf16_teacher_forced_agreement in test_hip_parity.py)."""
+    prompt, eot = g["prompt"].tolist(), int(g["eot"])
+    forced = g["forced_c"].tolist()
+    tc, lc = ctx.greedy_decode_resident_batch(wb.DecodeParams(prompt, len(forced) + 1, eot, forced=forced), want_logits=True)
+    errs = []
+    for r in rows:
+        assert len(lc[r]) == len(forced) + 1
+        assert np.isfinite(lc[r]).all()
+        for i in range(len(lc[r])):
+            errs.append(float(np.abs(lc[r][i][g["top_ids_c"][i]] - g["top_vals_c"][i]).max()))
+    worst = max(errs)
+    decided = agree = 0
+    for r in rows:
+        for i in range(len(lc[r])):
+            vals = g["top_vals_c"][i]
+            if vals[0] - vals[1] > 2.0 * worst:
+                decided += 1
+                agree += int(tc[r][len(prompt) + i] == g["tokens_c"][len(prompt) + i])
+    # all golden rows hold the same clip in the same context: identical to the last bit
+    for r in rows[1:]:
+        assert np.array_equal(lc[r], lc[rows[0]]), f"row {r} differs from row {rows[0]} (same clip, same context)"
+    print(f"{label}: max |logit - f32 golden| {worst:.4f}, mean {np.mean(errs):.4f} on logits of magnitude {np.abs(g['top_vals_c']).mean():.2f}; "
+          f"decided {decided} agree {agree}")
+    assert worst < err_bound, worst
+    assert agree == decided
+    return worst
+
+
+@pytest.mark.parametrize("nb", [1, 32, 256])
+def test_large_v3_bf16_teacher_forced_vs_golden(golden_dir, nb):
+    """BASELINE configs[3] in the dtype it names: bf16 at whisper-large-v3 size against the HF-pinned f32 golden vectors,
+    on a one-clip context (32 key ranges per clip and column group), a 32-clip context (3 key ranges) and a 256-clip
+    context (one key range: the attention kernel writes its own output) — the sizes of the profile lines.  This is what
+    puts k_dec_cross_attn_cg (bf16-only, d_model > 512), k_gemm8 at K = 1280 / 5120 (BN = 256 tiles), the 8-way-K decode
+    GEMMs and their wide variant under the golden vectors; the f32 test above takes k_dec_cross_attn and k_gemm."""
+    g = np.load(os.path.join(golden_dir, "large-v3_s5_c7.npz"))
+    model = wb.Model(f"synthetic:large-v3:{int(g['seed'])}", 0, wb.WH_PREC_BF16)
+    ctx = wb.Context(model, nb)
+    gold = ms.synth_clip(int(g["clip"]))
+    rows = sorted({0, nb // 2, nb - 1})
+    filler = [ms.synth_clip(40 + i) for i in range(min(nb, 5))]
+    clips = [gold if i in rows else filler[i % len(filler)] for i in range(nb)]
+    prompt, eot = g["prompt"].tolist(), int(g["eot"])
+    if nb == 1:   # encoder states of the one-clip context against the golden slices as well
+        mel = ctx.whisper_log_mel(gold)
+        np.testing.assert_allclose(mel[:, ::25], g["mel_slice"], rtol=0, atol=1e-4)
+        enc = ctx.run_encoder(mel)
+        enc_err = float(np.abs(enc[g["enc_rows"]] - g["enc_slice"]).max())
+        print(f"large-v3 bf16 encoder max abs err vs f32 golden {enc_err:.4f}")
+        assert enc_err < 0.2, enc_err
+    else:
+        ctx.transcribe_batch(clips, wb.DecodeParams(prompt, 1, eot))   # leaves the batch's encoder states resident
+    _teacher_forced_vs_golden(ctx, g, rows, f"large-v3 bf16, {nb}-clip context", 0.5)
+
+
+def test_large_v3_fp8_teacher_forced_vs_golden(golden_dir):
+    """The fp8 mode at whisper-large-v3 size against the f32 golden vectors (not against bf16-HIP): e4m3 weights, e4m3 cross
+    K/V, and — where the fp8-MFMA GEMM covers the contraction length — MX activations.  The bound is the measured error
+    with margin; e4m3 has 3 mantissa bits, so it is loose by construction."""
+    g = np.load(os.path.join(golden_dir, "large-v3_s5_c7.npz"))
+    model = wb.Model(f"synthetic:large-v3:{int(g['seed'])}", 0, wb.WH_PREC_FP8)
+    gold = ms.synth_clip(int(g["clip"]))
+    prompt, eot = g["prompt"].tolist(), int(g["eot"])
+    for nb in (1, 32):
+        ctx = wb.Context(model, nb)
+        rows = sorted({0, nb - 1})
+        clips = [gold if i in rows else ms.synth_clip(40 + (i % 5)) for i in range(nb)]
+        ctx.transcribe_batch(clips, wb.DecodeParams(prompt, 1, eot))
+        _teacher_forced_vs_golden(ctx, g, rows, f"large-v3 fp8, {nb}-clip context", 4.0)
+        ctx.close()
+
+
 def test_large_v3_bf16_runs_and_is_deterministic():
     model = wb.Model("synthetic:large-v3:5", 0, wb.WH_PREC_BF16)
     ctx = wb.Context(model, 4)

@@ -99,3 +99,40 @@ def test_bench_self_launches_one_rank_per_gpu():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--launch-check"],
                          env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "does not match --gpus" in bad.stderr
+
+
+def _clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+
+
+def test_bench_self_launch_at_eight_ranks_and_strong_scaling_split():
+    """The driver's N = 8 command shape on CPU (gloo rendezvous, no GPU work): eight children, every rank's records
+    gathered, and `--total-clips 512` (BASELINE configs[2]/[4]: 512 clips sharded over the GPUs) dealt as 64 per rank
+    with "scaling": "strong"; a clip count the ranks cannot share evenly is refused."""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--launch-check", "--total-clips", "512"],
+                         env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["world"] == 8 and line["max_rank"] == 7.0
+    assert line["scaling"] == "strong" and line["clips_per_gpu"] == 64
+    assert [c for c, _ in line["records"]] == list(range(16))
+    assert [t[0] for _, t in line["records"]] == [r for r in range(8) for _ in range(2)]
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--launch-check", "--total-clips", "100"],
+                         env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "not a multiple" in bad.stderr
+
+
+def test_bench_launcher_fails_when_one_rank_dies():
+    """One child exits with status 3 before the rendezvous: the launcher must return non-zero promptly, name the rank, and
+    end the other ranks (they would wait in the rendezvous for ever) instead of hanging."""
+    import subprocess
+    import time
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--launch-check", "--fail-rank", "2"],
+                         env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "rank 2 exited with 3" in out.stderr
+    assert not any(l.startswith("{") for l in out.stdout.splitlines())      # no result line from a failed job
+    assert time.time() - t0 < 120

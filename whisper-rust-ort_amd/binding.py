@@ -30,9 +30,9 @@ STATUS = {0: "WH_OK", 1: "WH_ERR_EMPTY_AUDIO", 2: "WH_ERR_BAD_SHAPE", 3: "WH_ERR
 
 # every symbol include/whisper_hip.h declares
 EXPORTS = ("wh_model_load", "wh_model_create", "wh_model_free", "wh_model_get_dims", "wh_model_precision",
-           "wh_model_export_tensor", "wh_ctx_create", "wh_ctx_free", "wh_last_error", "wh_get_timings",
+           "wh_model_export_tensor", "wh_ctx_create", "wh_ctx_create_ex", "wh_ctx_free", "wh_last_error", "wh_get_timings",
            "wh_mel_frames", "wh_log_mel", "wh_encode", "wh_decode_greedy", "wh_decode_greedy_batch", "wh_transcribe_batch",
-           "wh_transcribe_batch_device", "wh_longform_plan", "wh_transcribe_longform", "wh_profile_enable",
+           "wh_transcribe_batch_device", "wh_transcribe_batch_device_next", "wh_longform_plan", "wh_transcribe_longform", "wh_profile_enable",
            "wh_profile_get", "wh_synthetic_weights", "wh_e4m3_quantize", "wh_e4m3_dequantize", "wh_abi_version",
            "wh_device_count")
 
@@ -63,6 +63,28 @@ class WhClip(C.Structure):
     _fields_ = [("pcm", C.POINTER(C.c_float)), ("n_samples", C.c_size_t)]
 
 
+class WhCtxOpts(C.Structure):
+    _fields_ = [("struct_size", C.c_size_t), ("max_batch", C.c_int), ("flags", C.c_int),
+                ("enc_cu_mask", C.POINTER(C.c_uint32)), ("enc_cu_mask_words", C.c_size_t),
+                ("dec_cu_mask", C.POINTER(C.c_uint32)), ("dec_cu_mask_words", C.c_size_t)]
+
+
+WH_CTX_TWO_STREAMS = 1
+N_CUS = 256   # MI355X: 8 XCDs x 32 compute units
+
+
+def cu_mask(first: int, count: int, total: int = N_CUS) -> np.ndarray:
+    """CU mask words with bits first .. first+count-1 set.  On MI355X bit i is compute unit i // 8 of XCD i % 8
+    (tools/cu_mask_probe.hip), so a contiguous bit range whose ends are multiples of 8 takes the same number of
+    compute units from every XCD."""
+    if first < 0 or count < 1 or first + count > total:
+        raise ValueError(f"CU range [{first}, {first + count}) outside 0..{total}")
+    w = np.zeros((total + 31) // 32, np.uint32)
+    for i in range(first, first + count):
+        w[i >> 5] |= np.uint32(1 << (i & 31))
+    return w
+
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -83,6 +105,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.wh_model_precision.argtypes = [vp]
     L.wh_model_export_tensor.argtypes = [vp, C.c_char_p, f32p, C.c_size_t, szp]
     L.wh_ctx_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.wh_ctx_create_ex.argtypes = [vp, C.POINTER(WhCtxOpts), C.POINTER(vp)]
     L.wh_ctx_free.argtypes = [vp]
     L.wh_ctx_free.restype = None
     L.wh_last_error.argtypes = [vp]
@@ -96,6 +119,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.wh_decode_greedy_batch.argtypes = [vp, C.POINTER(WhDecodeParams), i64p, C.c_size_t, szp, C.c_size_t, szp, f32p, C.c_size_t]
     L.wh_transcribe_batch.argtypes = [vp, C.POINTER(WhClip), C.c_size_t, C.POINTER(WhDecodeParams), i64p, szp]
     L.wh_transcribe_batch_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(WhDecodeParams), i64p, szp]
+    L.wh_transcribe_batch_device_next.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(WhDecodeParams), i64p, szp]
     L.wh_longform_plan.argtypes = [C.c_size_t, C.c_double, C.c_double, szp, C.c_size_t, szp]
     L.wh_transcribe_longform.argtypes = [vp, f32p, C.c_size_t, C.c_double, C.c_double, C.POINTER(WhDecodeParams), i64p,
                                          szp, C.c_size_t, szp]
@@ -195,10 +219,22 @@ class Model:
 class Context:
     """One stream's workspace + KV cache (reference: per-thread IoBinding + `past`, src/main.rs:786-791)."""
 
-    def __init__(self, model: Model, max_batch: int = 1):
+    def __init__(self, model: Model, max_batch: int = 1, enc_cu_mask: Optional[np.ndarray] = None,
+                 dec_cu_mask: Optional[np.ndarray] = None, two_streams: bool = False):
+        """enc_cu_mask / dec_cu_mask (uint32 words, see cu_mask()) or two_streams: the chip-partition form of the context
+        (wh_ctx_create_ex) — log-mel + encoder on their own stream, beside the token loop of the previous batch."""
         self.model, self.lib, self.max_batch = model, model.lib, max_batch
         h = C.c_void_p()
-        rc = self.lib.wh_ctx_create(model.h, max_batch, C.byref(h))
+        if enc_cu_mask is None and dec_cu_mask is None and not two_streams:
+            rc = self.lib.wh_ctx_create(model.h, max_batch, C.byref(h))
+        else:
+            em = np.ascontiguousarray(enc_cu_mask, np.uint32) if enc_cu_mask is not None else None
+            dm = np.ascontiguousarray(dec_cu_mask, np.uint32) if dec_cu_mask is not None else None
+            u32p = C.POINTER(C.c_uint32)
+            o = WhCtxOpts(C.sizeof(WhCtxOpts), max_batch, WH_CTX_TWO_STREAMS if two_streams else 0,
+                          em.ctypes.data_as(u32p) if em is not None else None, em.size if em is not None else 0,
+                          dm.ctypes.data_as(u32p) if dm is not None else None, dm.size if dm is not None else 0)
+            rc = self.lib.wh_ctx_create_ex(model.h, C.byref(o), C.byref(h))
         if rc:
             raise WhisperHipError(rc, (self.lib.wh_last_error(None) or b"").decode())
         self.h = h
@@ -270,13 +306,19 @@ class Context:
         self._check(self.lib.wh_transcribe_batch(self.h, cl, len(arrs), C.byref(p), _i64(toks), n))
         return [toks[i, : n[i]].copy() for i in range(len(arrs))]
 
-    def transcribe_batch_device(self, d_pcm_ptr: int, n_clips: int, params: DecodeParams) -> List[np.ndarray]:
-        """PCM already resident in HBM: `d_pcm_ptr` = device address of [n_clips][480000] f32."""
+    def transcribe_batch_device(self, d_pcm_ptr: int, n_clips: int, params: DecodeParams, next_ptr: Optional[int] = None,
+                                next_n: int = 0) -> List[np.ndarray]:
+        """PCM already resident in HBM: `d_pcm_ptr` = device address of [n_clips][480000] f32.  next_ptr / next_n: the
+        batch whose log-mel + encoder are to run beside this batch's token loop (wh_transcribe_batch_device_next)."""
         p, keep = params.to_c()
         stride = len(params.prompt) + params.max_new_tokens
         toks = np.zeros((n_clips, stride), np.int64)
         n = (C.c_size_t * n_clips)()
-        self._check(self.lib.wh_transcribe_batch_device(self.h, C.c_void_p(d_pcm_ptr), n_clips, C.byref(p), _i64(toks), n))
+        if next_ptr is None:
+            self._check(self.lib.wh_transcribe_batch_device(self.h, C.c_void_p(d_pcm_ptr), n_clips, C.byref(p), _i64(toks), n))
+        else:
+            self._check(self.lib.wh_transcribe_batch_device_next(self.h, C.c_void_p(d_pcm_ptr), n_clips, C.c_void_p(next_ptr), next_n,
+                                                                 C.byref(p), _i64(toks), n))
         return [toks[i, : n[i]].copy() for i in range(n_clips)]
 
     def transcribe_longform(self, audio_16k: np.ndarray, params: DecodeParams, chunk_length_s: float = 30.0,
@@ -369,3 +411,35 @@ def e4m3_dequantize(codes: np.ndarray) -> np.ndarray:
 
 def device_count() -> int:
     return int(load_library().wh_device_count())
+
+
+class HipRuntime:
+    """Just enough of the HIP runtime (the instance libwhisper_hip.so already loaded) to keep PCM resident in HBM for
+    wh_transcribe_batch_device: bench.py and the GPU tests of that entry."""
+
+    def __init__(self):
+        load_library()
+        self.lib = C.CDLL("libamdhip64.so.7", mode=C.RTLD_GLOBAL)
+        self.lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.lib.hipFree.argtypes = [C.c_void_p]
+        self.lib.hipSetDevice.argtypes = [C.c_int]
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed with hipError {rc}")
+
+    def upload(self, dev: int, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr)
+        self.check(self.lib.hipSetDevice(dev), "hipSetDevice")
+        p = C.c_void_p()
+        self.check(self.lib.hipMalloc(C.byref(p), arr.nbytes), "hipMalloc")
+        self.check(self.lib.hipMemcpy(p, arr.ctypes.data_as(C.c_void_p), arr.nbytes, 1), "hipMemcpy H2D")
+        self.check(self.lib.hipDeviceSynchronize(), "hipDeviceSynchronize")
+        return p.value
+
+    def free(self, ptr: int):
+        self.check(self.lib.hipFree(C.c_void_p(ptr)), "hipFree")
+
+    def sync(self):
+        self.check(self.lib.hipDeviceSynchronize(), "hipDeviceSynchronize")

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <functional>
 
 #include "wh_common.h"
 #include "wh_internal.h"
@@ -65,10 +66,10 @@ struct Prof {
             v.push_back({a, b});
         }
         slot = c->prof_used[g]++;
-        hipEventRecord(v[slot].first, c->stream);
+        hipEventRecord(v[slot].first, c->cur);
     }
     ~Prof() {
-        if (on) hipEventRecord(c->prof_events[g][slot].second, c->stream);
+        if (on) hipEventRecord(c->prof_events[g][slot].second, c->cur);
     }
 };
 
@@ -100,10 +101,19 @@ struct Carver {
 };
 
 // ---- encoder for nb clips whose conv1 operand already sits in c->melT ---------------------------
+// An encoder pass (log-mel included) is about to overwrite the encoder-side workspace: it must not start before the
+// cross-K/V projection of the previous batch has read the encoder states.  No-op when both phases share one stream.
+int enc_begin(wh_ctx* c) {
+    c->cur = c->s_enc;
+    if (c->kv_done_armed && c->s_enc != c->stream) CTX_HIP(c, hipStreamWaitEvent(c->s_enc, c->ev_kv_done, 0));
+    return WH_OK;
+}
+
 int run_encoder(wh_ctx* c, int nb, bool want_f32) {
     wh_model* m = c->m;
     const wh_dims& D = m->dims;
-    hipStream_t s = c->stream;
+    hipStream_t s = c->s_enc;
+    c->cur = s;
     const int prec = m->prec;
     const long d = D.d_model, S = D.n_audio_ctx, F = D.ffn, C = D.n_mels;
     const size_t esz = m->esz;
@@ -135,7 +145,7 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
         const EncLayerDev& L = m->enc[l];
         // WH_PREC_FP8 with MX activations: LayerNorm writes e4m3 codes + block exponents and the three GEMMs it feeds run
         // on the fp8 matrix cores (e4m3 weights x MX activations); otherwise bf16 operands (fp8 weights as code values)
-        const bool mx = c->mx_ok && rows >= 256;
+        const bool mx = c->mx_ok;
         {
             Prof p(c, WH_KG_ENC_GEMM);
             if (mx) wh_launch_layernorm_mx(s, c->x, L.ln1_w, L.ln1_b, c->xn8, c->xn8_sc, rows, (int)d);
@@ -200,14 +210,15 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
     }
     {
         Prof p(c, WH_KG_ENC_GEMM);
-        wh_launch_layernorm(s, prec, c->x, m->enc_ln_w, m->enc_ln_b, c->enc_out, rows, (int)d);
-        if (c->mx_ok && rows >= 256)   // the cross K/V projection's operand in MX form
-            wh_launch_layernorm_mx(s, c->x, m->enc_ln_w, m->enc_ln_b, c->xn8, c->xn8_sc, rows, (int)d);
+        // the cross K/V projection's operand: MX form when that GEMM runs on the fp8 matrix cores, else the compute dtype
+        if (c->mx_ok) wh_launch_layernorm_mx(s, c->x, m->enc_ln_w, m->enc_ln_b, c->xn8, c->xn8_sc, rows, (int)d);
+        else wh_launch_layernorm(s, prec, c->x, m->enc_ln_w, m->enc_ln_b, c->enc_out, rows, (int)d);
         if (want_f32) {
             if (prec == WH_PREC_F32) hipMemcpyAsync(c->enc_out_f32, c->enc_out, rows * d * 4, hipMemcpyDeviceToDevice, s);
             else wh_launch_layernorm(s, WH_PREC_F32, c->x, m->enc_ln_w, m->enc_ln_b, c->enc_out_f32, rows, (int)d);
         }
     }
+    CTX_HIP(c, hipEventRecord(c->ev_enc_done, s));
     c->have_enc = true;
     c->enc_batch = nb;
     return WH_OK;
@@ -231,11 +242,15 @@ void pack_mask(const int64_t* a, size_t na, const int64_t* b, size_t nb, int voc
 }
 
 // ---- cross-KV + greedy loop for the nb clips whose encoder states are resident ------------------
+// `after_kv` (optional) runs on the host right after the cross-K/V projection has been enqueued and its completion event
+// recorded: the place where the NEXT batch's encoder pass is put on the encoder stream, before the host is tied up in the
+// token loop.
 int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out, size_t tok_stride,
-               size_t* n_tokens_out, float* logits_out, size_t logits_rows) {
+               size_t* n_tokens_out, float* logits_out, size_t logits_rows, const std::function<int()>& after_kv = nullptr) {
     wh_model* m = c->m;
     const wh_dims& D = m->dims;
     hipStream_t s = c->stream;
+    c->cur = s;
     const int prec = m->prec;
     const long d = D.d_model, S = D.n_audio_ctx, F = D.ffn;
     const size_t esz = m->esz;
@@ -248,6 +263,9 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     for (size_t i = 0; i < p->n_forced; i++)
         if (p->forced[i] < 0 || p->forced[i] >= D.vocab) return fail(c, WH_ERR_ARG, "decode: forced id outside the vocabulary");
 
+    // the encoder states come from the encoder stream
+    if (c->s_enc != s) CTX_HIP(c, hipStreamWaitEvent(s, c->ev_enc_done, 0));
+    CTX_HIP(c, hipEventRecord(c->ev[5], s));   // decode start (stage timing)
     // token state
     const int ld = c->tok_ld;
     std::vector<int> feed((size_t)nb * ld, 0);
@@ -299,13 +317,20 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
         g.C = c->cross_kv; g.ldc = d; g.n_per = (int)d; g.c_ns = kv_stride;
         g.bias = m->cross_kv_b; g.bias_mode = 1; g.wscale = m->cross_kv_sc;
         g.M = nb * (int)S; g.N = (int)(D.dec_layers * 2 * d); g.K = (int)d;
-        if (c->mx_ok && g.M >= 256) { g.A = c->xn8; g.a_sc = c->xn8_sc; g.W = m->cross_kv_w8; wh_launch_gemm8_mx(s, 0, g); }   // xn8 = MX(final LN), run_encoder
+        if (c->mx_ok) { g.A = c->xn8; g.a_sc = c->xn8_sc; g.W = m->cross_kv_w8; wh_launch_gemm8_mx(s, 0, g); }   // xn8 = MX(final LN), run_encoder
         else wh_launch_gemm(s, prec, false, g);
         if (f8) {  // bf16 projection → e4m3 codes, one scale per (layer, K|V, clip, head)
             const long planes = (long)D.dec_layers * 2 * nb;
             CTX_HIP(c, hipMemsetAsync(c->kv_amax, 0, planes * D.n_heads * 4, s));
             wh_launch_kv_quant(s, c->cross_kv, (unsigned*)c->kv_amax, c->cross_kv8, planes, (int)S, (int)d, D.n_heads);
         }
+    }
+    CTX_HIP(c, hipEventRecord(c->ev_kv_done, s));   // the encoder-side workspace may be overwritten from here on
+    c->kv_done_armed = true;
+    if (after_kv) {
+        int rc = after_kv();
+        if (rc) return rc;
+        c->cur = s;
     }
 
     DecodeState st;
@@ -508,14 +533,15 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     return WH_OK;
 }
 
-// mel of nb clips resident in c->pcm (n samples each in c->d_nsamp) → conv1 operand in c->melT
-int run_mel_batch(wh_ctx* c, int nb) {
+// mel of nb clips resident at `pcm` ([nb][480000] f32, n samples each in c->d_nsamp) → conv1 operand in c->melT
+int run_mel_batch(wh_ctx* c, const float* pcm, int nb) {
     wh_model* m = c->m;
-    hipStream_t s = c->stream;
+    hipStream_t s = c->s_enc;
+    c->cur = s;
     CTX_HIP(c, hipMemsetAsync(c->d_gmax, 0, nb * 4, s));
     {
         Prof p(c, WH_KG_MEL);
-        wh_launch_mel_stft(s, c->pcm, WH_CLIP_SAMPLES, c->d_nsamp, nb, WH_N_FRAMES, m->mel_tw, m->mel_win, m->mel_fbT,
+        wh_launch_mel_stft(s, pcm, WH_CLIP_SAMPLES, c->d_nsamp, nb, WH_N_FRAMES, m->mel_tw, m->mel_win, m->mel_fbT,
                            m->dims.n_mels, c->raw, (long)m->dims.n_mels * RAW_LD, RAW_LD, c->d_gmax);
     }
     {
@@ -530,11 +556,27 @@ int run_mel_batch(wh_ctx* c, int nb) {
     return WH_OK;
 }
 
+// log-mel + encoder of nb resident clips as one pass on the encoder stream, stage events into set `set`
+int run_encoder_pass(wh_ctx* c, const float* pcm, int nb, int set) {
+    int rc = enc_begin(c);
+    if (rc) return rc;
+    hipStream_t s = c->s_enc;
+    CTX_HIP(c, hipEventRecord(c->enc_ev[set][0], s));
+    rc = run_mel_batch(c, pcm, nb);
+    if (rc) return rc;
+    CTX_HIP(c, hipEventRecord(c->enc_ev[set][1], s));
+    rc = run_encoder(c, nb, false);
+    if (rc) return rc;
+    CTX_HIP(c, hipEventRecord(c->enc_ev[set][2], s));
+    return WH_OK;
+}
+
+// stage times of the batch whose encoder pass is in event set c->enc_set and whose decode ran between ev[5] and ev[3]
 int finish_timing(wh_ctx* c, double t_start) {
     float a = 0, b = 0, d = 0;
-    hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
-    hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
-    hipEventElapsedTime(&d, c->ev[2], c->ev[3]);
+    hipEventElapsedTime(&a, c->enc_ev[c->enc_set][0], c->enc_ev[c->enc_set][1]);
+    hipEventElapsedTime(&b, c->enc_ev[c->enc_set][1], c->enc_ev[c->enc_set][2]);
+    hipEventElapsedTime(&d, c->ev[5], c->ev[3]);
     c->timing.preprocess_s = a * 1e-3;
     c->timing.encode_s = b * 1e-3;
     c->timing.decode_s = d * 1e-3;
@@ -638,9 +680,28 @@ int wh_model_export_tensor(const wh_model* m, const char* name, float* out, size
 }
 
 int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
-    if (!m || !out) { wh_set_error("wh_ctx_create: NULL argument"); return WH_ERR_ARG; }
+    wh_ctx_opts o{};
+    o.struct_size = sizeof o;
+    o.max_batch = max_batch;
+    return wh_ctx_create_ex(m, &o, out);
+}
+
+int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
+    if (!m || !out || !opts) { wh_set_error("wh_ctx_create: NULL argument"); return WH_ERR_ARG; }
     *out = nullptr;
+    if (opts->struct_size != sizeof(wh_ctx_opts)) { wh_set_error("wh_ctx_create_ex: wh_ctx_opts.struct_size does not match this library"); return WH_ERR_ARG; }
+    const int max_batch = opts->max_batch;
     if (max_batch < 1 || max_batch > WH_MAX_BATCH) { wh_set_error("max_batch must be 1..1024"); return WH_ERR_ARG; }
+    if ((opts->enc_cu_mask_words && !opts->enc_cu_mask) || (opts->dec_cu_mask_words && !opts->dec_cu_mask)) {
+        wh_set_error("wh_ctx_create_ex: NULL CU mask with a non-zero word count");
+        return WH_ERR_ARG;
+    }
+    auto mask_bits = [](const uint32_t* w, size_t n) { size_t k = 0; for (size_t i = 0; i < n; i++) k += (size_t)__builtin_popcount(w[i]); return k; };
+    if ((opts->enc_cu_mask_words && mask_bits(opts->enc_cu_mask, opts->enc_cu_mask_words) == 0) ||
+        (opts->dec_cu_mask_words && mask_bits(opts->dec_cu_mask, opts->dec_cu_mask_words) == 0)) {
+        wh_set_error("wh_ctx_create_ex: a CU mask with no bit set would leave its stream without compute units");
+        return WH_ERR_ARG;
+    }
     WH_HIP_CHECK(hipSetDevice(m->device));
     auto* c = new wh_ctx();
     c->m = m;
@@ -651,7 +712,9 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
     const size_t Ld = D.dec_layers, H = D.n_heads, TC = D.n_text_ctx;
     c->ldv = (int)align_up(S, 64);
     c->tok_ld = D.n_text_ctx + 1;
-    c->mpad = (int)align_up(B, 16);
+    // row pitch of the slab-layout decode activations: the decode GEMMs read whole 32- / 64-row groups (k_dec_gemm MT = 2,
+    // k_dec_gemm_wide MT = 4) whose tail rows are masked, not clamped — the pitch covers them
+    c->mpad = (int)align_up(B, B > 16 ? 64 : 16);
     // enough workgroups to cover the chip at small batch, no more than 16 key ranges
     c->cross_splits = (int)std::min<size_t>(32, std::max<size_t>(1, 256 / B));  // measured: ~256 workgroups streams best
     if (m->prec == WH_PREC_BF16 && d > 512 && d % 256 == 0)   // wide models: a workgroup per 256-column group as well (k_dec_cross_attn_cg)
@@ -668,17 +731,18 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
     const bool f8 = m->prec == WH_PREC_FP8;
     const size_t o_ckv8 = f8 ? cv.take(Ld * 2 * B * S * d) : 0, o_kvam = f8 ? cv.take(Ld * 2 * B * H * 4) : 0;
     // fp8-MFMA encoder (wh_gemm8_mx.hip): MX activations when every contraction length is one the kernel takes
+    // (decided from the model and the context only, never from a call's clip count: S >= 256 rows is one full tile even for one clip)
     auto mx_k = [](size_t k) { return k == 256 || k == 512 || k == 1024 || k == 2048; };
-    c->mx_ok = f8 && mx_k(d) && mx_k(F) && (d % 256) == 0 && getenv("WH_NO_MX") == nullptr;
+    c->mx_ok = f8 && mx_k(d) && mx_k(F) && (d % 256) == 0 && S >= 256 && getenv("WH_NO_MX") == nullptr;
     const size_t o_xn8 = c->mx_ok ? cv.take(B * S * d) : 0, o_xn8s = c->mx_ok ? cv.take(B * S * d / 32) : 0;
     const size_t o_h8 = c->mx_ok ? cv.take(B * S * F) : 0, o_h8s = c->mx_ok ? cv.take(B * S * F / 32) : 0;
     const size_t o_sk = cv.take(Ld * B * H * TC * WH_HEAD_DIM * esz), o_sv = cv.take(Ld * B * H * TC * WH_HEAD_DIM * esz);
-    const size_t MP = align_up(B, 16);  // slab-layout activations: [K/32][MP][32]
+    const size_t MP = (size_t)c->mpad;  // slab-layout activations: [K/32][MP][32]
     const size_t o_dx = cv.take(B * d * 4), o_dxn = cv.take(MP * d * esz), o_dqkv = cv.take(B * 3 * d * esz);
     const size_t o_dxs = cv.take(MP * d * esz), o_lnp = cv.take((d / 16) * MP * 2 * 4);
     const size_t o_datt = cv.take(MP * d * esz), o_dq = cv.take(B * d * esz), o_dh = cv.take(MP * F * esz);
     const size_t o_cpart = cv.take(B * c->cross_splits * d * 4), o_cml = cv.take(B * c->cross_splits * H * 2 * 4);
-    const size_t o_pv = cv.take(align_up(B, 16) * (n_tiles + 4) * 4), o_pi = cv.take(align_up(B, 16) * (n_tiles + 4) * 4);  // [part][mpad]
+    const size_t o_pv = cv.take(MP * (n_tiles + 4) * 4), o_pi = cv.take(MP * (n_tiles + 4) * 4);  // [part][mpad]
     const size_t o_feed = cv.take(B * c->tok_ld * 4), o_out = cv.take(B * c->tok_ld * 4);
     const size_t o_nout = cv.take(B * 4), o_done = cv.take(B * 4), o_forced = cv.take(TC * 4), o_pos = cv.take(4);
     const size_t o_stk = cv.take(4);
@@ -707,10 +771,24 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
     c->mask_first = (unsigned*)(w + o_m1); c->mask_base = (unsigned*)(w + o_m2);
     c->d_nsamp = (int*)(w + o_ns); c->d_nframes = (int*)(w + o_nf); c->d_src_index = (int*)(w + o_si);
     c->d_frame_start = (int*)(w + o_fs); c->d_gmax = (unsigned*)(w + o_gm);
-    he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    // streams: one for everything, or — chip partition — the token loop on `stream` and log-mel + encoder on `s_enc`, each
+    // optionally confined to a set of compute units (hipExtStreamCreateWithCUMask: bit i of the mask is compute unit
+    // i / 8 of XCD i % 8 on this part, tools/cu_mask_probe.hip)
+    if (opts->dec_cu_mask_words) he = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)opts->dec_cu_mask_words, opts->dec_cu_mask);
+    else he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (he != hipSuccess) { hipFree(c->ws); delete c; return wh_fail_hip(he, "hipStreamCreate", __FILE__, __LINE__); }
+    c->s_enc = c->stream;
+    if (opts->enc_cu_mask_words || (opts->flags & WH_CTX_TWO_STREAMS)) {
+        if (opts->enc_cu_mask_words) he = hipExtStreamCreateWithCUMask(&c->s_enc, (uint32_t)opts->enc_cu_mask_words, opts->enc_cu_mask);
+        else he = hipStreamCreateWithFlags(&c->s_enc, hipStreamNonBlocking);
+        if (he != hipSuccess) { hipStreamDestroy(c->stream); hipFree(c->ws); delete c; return wh_fail_hip(he, "hipStreamCreate(encoder stream)", __FILE__, __LINE__); }
+    }
+    c->cur = c->stream;
     for (auto& e : c->ev) hipEventCreate(&e);
-    // the cross-attention kernel may need more than the default dynamic LDS
+    for (auto& set : c->enc_ev)
+        for (auto& e : set) hipEventCreate(&e);
+    hipEventCreateWithFlags(&c->ev_enc_done, hipEventDisableTiming);
+    hipEventCreateWithFlags(&c->ev_kv_done, hipEventDisableTiming);
     *out = c;
     return WH_OK;
 }
@@ -718,12 +796,19 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out) {
 void wh_ctx_free(wh_ctx* c) {
     if (!c) return;
     hipSetDevice(c->m->device);
+    if (c->s_enc && c->s_enc != c->stream) hipStreamSynchronize(c->s_enc);   // a prefetched encoder pass may be in flight
     if (c->stream) hipStreamSynchronize(c->stream);
     drop_step_graph(c);
     for (int g = 0; g < WH_KG_COUNT; g++)
         for (auto& e : c->prof_events[g]) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : c->ev)
         if (e) hipEventDestroy(e);
+    for (auto& set : c->enc_ev)
+        for (auto& e : set)
+            if (e) hipEventDestroy(e);
+    if (c->ev_enc_done) hipEventDestroy(c->ev_enc_done);
+    if (c->ev_kv_done) hipEventDestroy(c->ev_kv_done);
+    if (c->s_enc && c->s_enc != c->stream) hipStreamDestroy(c->s_enc);
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->ws) hipFree(c->ws);
     if (c->pcm_long) hipFree(c->pcm_long);
@@ -783,7 +868,9 @@ static int whole_file_mel(wh_ctx* c, const float* pcm, size_t n, size_t* nf_out,
     const size_t nf = wh_mel_frames(n), ld = align_up(nf, 16);
     int rc = ensure_long(c, n, nf);
     if (rc) return rc;
-    hipStream_t s = c->stream;
+    rc = enc_begin(c);
+    if (rc) return rc;
+    hipStream_t s = c->s_enc;
     const int ni = (int)n, nfi = (int)nf;
     CTX_HIP(c, hipMemcpyAsync(c->pcm_long, pcm, n * 4, hipMemcpyHostToDevice, s));
     CTX_HIP(c, hipMemcpyAsync(c->d_nsamp, &ni, 4, hipMemcpyHostToDevice, s));
@@ -810,9 +897,10 @@ int wh_log_mel(wh_ctx* c, const float* pcm, size_t n, float* mel_out, size_t cap
     if (rc) return rc;
     if (n_frames_out) *n_frames_out = nf;
     if (!mel_out || cap_frames < nf) return fail(c, WH_ERR_ARG, "mel_out too small: %zu frames needed", nf);
-    wh_launch_mel_norm(c->stream, c->raw_long, (long)ld, c->d_gmax, c->m->dims.n_mels, (long)nf, c->mel_out_long);
-    CTX_HIP(c, hipMemcpyAsync(mel_out, c->mel_out_long, (size_t)c->m->dims.n_mels * nf * 4, hipMemcpyDeviceToHost, c->stream));
-    CTX_HIP(c, hipStreamSynchronize(c->stream));
+    hipStream_t s = c->s_enc;
+    wh_launch_mel_norm(s, c->raw_long, (long)ld, c->d_gmax, c->m->dims.n_mels, (long)nf, c->mel_out_long);
+    CTX_HIP(c, hipMemcpyAsync(mel_out, c->mel_out_long, (size_t)c->m->dims.n_mels * nf * 4, hipMemcpyDeviceToHost, s));
+    CTX_HIP(c, hipStreamSynchronize(s));
     CTX_HIP(c, hipGetLastError());
     c->timing = wh_timing{};
     c->timing.preprocess_s = c->timing.total_s = now_s() - t0;
@@ -827,7 +915,10 @@ int wh_encode(wh_ctx* c, const float* mel, float* enc_out) {
     prof_reset(c);
     const double t0 = now_s();
     const wh_dims& D = c->m->dims;
-    hipStream_t s = c->stream;
+    int rc = enc_begin(c);
+    if (rc) return rc;
+    hipStream_t s = c->s_enc;
+    c->pre_valid = false;   // the resident encoder states are replaced
     const int nf = WH_N_FRAMES;
     CTX_HIP(c, hipMemcpyAsync(c->mel_stage, mel, (size_t)D.n_mels * WH_N_FRAMES * 4, hipMemcpyHostToDevice, s));
     CTX_HIP(c, hipMemcpyAsync(c->d_nframes, &nf, 4, hipMemcpyHostToDevice, s));
@@ -839,7 +930,7 @@ int wh_encode(wh_ctx* c, const float* mel, float* enc_out) {
     else
         wh_launch_mel_tokens<bf16>(s, c->mel_stage, 0, WH_N_FRAMES, nullptr, nullptr, c->d_nframes, nullptr, 1, D.n_mels, 1,
                                    (bf16*)c->melT, (long)TOK_ROWS * D.n_mels);
-    int rc = run_encoder(c, 1, enc_out != nullptr);
+    rc = run_encoder(c, 1, enc_out != nullptr);
     if (rc) return rc;
     CTX_HIP(c, hipEventRecord(c->ev[2], s));
     if (enc_out)
@@ -855,6 +946,18 @@ int wh_encode(wh_ctx* c, const float* mel, float* enc_out) {
     return WH_OK;
 }
 
+// stage times of a decode-only call (run_decode brackets the decode with ev[5] .. ev[3])
+static void decode_only_timing(wh_ctx* c, double t0) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, c->ev[5], c->ev[3]);
+    const double d2h = c->timing.d2h_s;
+    c->timing = wh_timing{};
+    c->timing.decode_s = ms * 1e-3;
+    c->timing.d2h_s = d2h;
+    c->timing.total_s = now_s() - t0;
+    prof_collect(c);
+}
+
 int wh_decode_greedy(wh_ctx* c, const wh_decode_params* p, int64_t* tokens_out, size_t cap_tokens, size_t* n_tokens_out,
                      float* logits_out, size_t cap_logits_rows) {
     if (!c) return WH_ERR_ARG;
@@ -867,17 +970,9 @@ int wh_decode_greedy(wh_ctx* c, const wh_decode_params* p, int64_t* tokens_out, 
     CTX_HIP(c, hipSetDevice(c->m->device));
     prof_reset(c);
     const double t0 = now_s();
-    CTX_HIP(c, hipEventRecord(c->ev[2], c->stream));
     rc = run_decode(c, 1, p, tokens_out, cap_tokens, n_tokens_out, logits_out, p->max_new_tokens);
     if (rc) return rc;
-    float ms = 0;
-    hipEventElapsedTime(&ms, c->ev[2], c->ev[3]);
-    const double d2h = c->timing.d2h_s;
-    c->timing = wh_timing{};
-    c->timing.decode_s = ms * 1e-3;
-    c->timing.d2h_s = d2h;
-    c->timing.total_s = now_s() - t0;
-    prof_collect(c);
+    decode_only_timing(c, t0);
     return WH_OK;
 }
 
@@ -887,6 +982,7 @@ int wh_decode_greedy_batch(wh_ctx* c, const wh_decode_params* p, int64_t* tokens
     int rc = check_params(c, p);
     if (rc) return rc;
     if (!c->have_enc) return fail(c, WH_ERR_STATE, "Missing cached decoder input: encoder states (call wh_transcribe_batch or wh_encode first)");
+    if (c->pre_valid) return fail(c, WH_ERR_STATE, "the resident encoder states belong to a prefetched batch that has not been transcribed yet");
     const int nb = c->enc_batch;
     if (n_clips_out) *n_clips_out = (size_t)nb;
     if (!tokens_out || !n_tokens_out || cap_clips < (size_t)nb || cap_tokens < p->n_prompt + p->max_new_tokens)
@@ -895,33 +991,48 @@ int wh_decode_greedy_batch(wh_ctx* c, const wh_decode_params* p, int64_t* tokens
     CTX_HIP(c, hipSetDevice(c->m->device));
     prof_reset(c);
     const double t0 = now_s();
-    CTX_HIP(c, hipEventRecord(c->ev[2], c->stream));
     rc = run_decode(c, nb, p, tokens_out, cap_tokens, n_tokens_out, logits_out, logits_out ? cap_logits_rows : 0);
     if (rc) return rc;
-    float ms = 0;
-    hipEventElapsedTime(&ms, c->ev[2], c->ev[3]);
-    const double d2h = c->timing.d2h_s;
-    c->timing = wh_timing{};
-    c->timing.decode_s = ms * 1e-3;
-    c->timing.d2h_s = d2h;
-    c->timing.total_s = now_s() - t0;
-    prof_collect(c);
+    decode_only_timing(c, t0);
     return WH_OK;
 }
 
-static int transcribe_resident(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out, size_t* n_tokens_out,
-                               double t_start) {
-    hipStream_t s = c->stream;
-    CTX_HIP(c, hipEventRecord(c->ev[0], s));
-    int rc = run_mel_batch(c, nb);
+// Clips resident at `pcm` on the device → tokens.  The encoder pass of this batch runs now unless `prefetched`; if
+// `next_pcm` is given, the NEXT batch's log-mel + encoder are put on the encoder stream as soon as this batch's cross-K/V
+// projection has been enqueued, i.e. they run beside this batch's token loop.
+static int transcribe_resident(wh_ctx* c, const float* pcm, int nb, bool prefetched, const float* next_pcm, int next_nb,
+                               const wh_decode_params* p, int64_t* tokens_out, size_t* n_tokens_out, double t_start) {
+    int rc;
+    if (!prefetched) {
+        c->pre_valid = false;
+        rc = run_encoder_pass(c, pcm, nb, c->enc_set);
+        if (rc) return rc;
+    }
+    std::function<int()> hook;
+    if (next_pcm) {
+        hook = [c, next_pcm, next_nb]() -> int {
+            // every clip of a device-resident batch is exactly 30 s: fill the per-clip sample / frame counts on the stream
+            hipStream_t se = c->s_enc;
+            int rc2 = enc_begin(c);
+            if (rc2) return rc2;
+            CTX_HIP(c, hipMemsetD32Async((hipDeviceptr_t)c->d_nsamp, WH_CLIP_SAMPLES, next_nb, se));
+            CTX_HIP(c, hipMemsetD32Async((hipDeviceptr_t)c->d_nframes, WH_N_FRAMES, next_nb, se));
+            rc2 = run_encoder_pass(c, next_pcm, next_nb, c->enc_set ^ 1);
+            if (rc2) return rc2;
+            c->pre_pcm = next_pcm;
+            c->pre_n = next_nb;
+            c->pre_valid = true;
+            return WH_OK;
+        };
+    }
+    rc = run_decode(c, nb, p, tokens_out, p->n_prompt + p->max_new_tokens, n_tokens_out, nullptr, 0, hook);
     if (rc) return rc;
-    CTX_HIP(c, hipEventRecord(c->ev[1], s));
-    rc = run_encoder(c, nb, false);
-    if (rc) return rc;
-    CTX_HIP(c, hipEventRecord(c->ev[2], s));
-    rc = run_decode(c, nb, p, tokens_out, p->n_prompt + p->max_new_tokens, n_tokens_out, nullptr, 0);
-    if (rc) return rc;
-    return finish_timing(c, t_start);
+    rc = finish_timing(c, t_start);
+    if (c->pre_valid) {          // the resident states are now the prefetched batch's
+        c->enc_set ^= 1;
+        c->enc_batch = c->pre_n;
+    }
+    return rc;
 }
 
 int wh_transcribe_batch(wh_ctx* c, const wh_clip* clips, size_t n_clips, const wh_decode_params* p, int64_t* tokens_out,
@@ -934,7 +1045,9 @@ int wh_transcribe_batch(wh_ctx* c, const wh_clip* clips, size_t n_clips, const w
     CTX_HIP(c, hipSetDevice(c->m->device));
     prof_reset(c);
     const double t0 = now_s();
-    hipStream_t s = c->stream;
+    rc = enc_begin(c);
+    if (rc) return rc;
+    hipStream_t s = c->s_enc;
     std::vector<int> ns(n_clips), nf(n_clips);
     for (size_t i = 0; i < n_clips; i++) {
         if (clips[i].n_samples == 0) return fail(c, WH_ERR_EMPTY_AUDIO, "Empty audio");
@@ -949,30 +1062,37 @@ int wh_transcribe_batch(wh_ctx* c, const wh_clip* clips, size_t n_clips, const w
     CTX_HIP(c, hipStreamSynchronize(s));
     c->timing = wh_timing{};
     c->timing.h2d_s = now_s() - t0;
-    return transcribe_resident(c, (int)n_clips, p, tokens_out, n_tokens_out, t0);
+    return transcribe_resident(c, c->pcm, (int)n_clips, false, nullptr, 0, p, tokens_out, n_tokens_out, t0);
 }
 
-int wh_transcribe_batch_device(wh_ctx* c, const float* d_pcm, size_t n_clips, const wh_decode_params* p,
-                               int64_t* tokens_out, size_t* n_tokens_out) {
+int wh_transcribe_batch_device_next(wh_ctx* c, const float* d_pcm, size_t n_clips, const float* d_pcm_next, size_t n_clips_next,
+                                    const wh_decode_params* p, int64_t* tokens_out, size_t* n_tokens_out) {
     if (!c) return WH_ERR_ARG;
     int rc = check_params(c, p);
     if (rc) return rc;
     if (!d_pcm || !tokens_out || !n_tokens_out) return fail(c, WH_ERR_ARG, "NULL argument");
     if (n_clips == 0 || n_clips > (size_t)c->max_batch) return fail(c, WH_ERR_ARG, "n_clips must be 1..max_batch (%d)", c->max_batch);
+    if (d_pcm_next && (n_clips_next == 0 || n_clips_next > (size_t)c->max_batch))
+        return fail(c, WH_ERR_ARG, "n_clips_next must be 1..max_batch (%d)", c->max_batch);
     CTX_HIP(c, hipSetDevice(c->m->device));
     prof_reset(c);
     const double t0 = now_s();
-    hipStream_t s = c->stream;
-    std::vector<int> ns(n_clips, WH_CLIP_SAMPLES), nf(n_clips, WH_N_FRAMES);
-    CTX_HIP(c, hipMemcpyAsync(c->d_nsamp, ns.data(), n_clips * 4, hipMemcpyHostToDevice, s));
-    CTX_HIP(c, hipMemcpyAsync(c->d_nframes, nf.data(), n_clips * 4, hipMemcpyHostToDevice, s));
-    CTX_HIP(c, hipStreamSynchronize(s));
-    float* saved = c->pcm;
-    c->pcm = const_cast<float*>(d_pcm);  // kernels only read it
+    // encoder states of exactly this batch already resident (prefetched by the previous call)?
+    const bool prefetched = c->pre_valid && c->pre_pcm == d_pcm && c->pre_n == (int)n_clips;
+    if (!prefetched) {
+        rc = enc_begin(c);
+        if (rc) return rc;
+        CTX_HIP(c, hipMemsetD32Async((hipDeviceptr_t)c->d_nsamp, WH_CLIP_SAMPLES, n_clips, c->s_enc));
+        CTX_HIP(c, hipMemsetD32Async((hipDeviceptr_t)c->d_nframes, WH_N_FRAMES, n_clips, c->s_enc));
+    }
+    c->pre_valid = false;
     c->timing = wh_timing{};
-    rc = transcribe_resident(c, (int)n_clips, p, tokens_out, n_tokens_out, t0);
-    c->pcm = saved;
-    return rc;
+    return transcribe_resident(c, d_pcm, (int)n_clips, prefetched, d_pcm_next, (int)n_clips_next, p, tokens_out, n_tokens_out, t0);
+}
+
+int wh_transcribe_batch_device(wh_ctx* c, const float* d_pcm, size_t n_clips, const wh_decode_params* p,
+                               int64_t* tokens_out, size_t* n_tokens_out) {
+    return wh_transcribe_batch_device_next(c, d_pcm, n_clips, nullptr, 0, p, tokens_out, n_tokens_out);
 }
 
 int wh_longform_plan(size_t n_samples, double chunk_length_s, double overlap_s, size_t* offsets, size_t cap,
@@ -1005,7 +1125,8 @@ int wh_transcribe_longform(wh_ctx* c, const float* pcm, size_t n_samples, double
     CTX_HIP(c, hipSetDevice(c->m->device));
     prof_reset(c);
     const double t0 = now_s();
-    hipStream_t s = c->stream;
+    hipStream_t s = c->s_enc;   // whole-file mel, window cut and encoder; run_decode uses the decode stream
+    c->pre_valid = false;
     size_t nch = 0;
     wh_longform_plan(n_samples, chunk_length_s, overlap_s, nullptr, 0, &nch);
     *n_chunks_out = nch;
@@ -1026,6 +1147,8 @@ int wh_transcribe_longform(wh_ctx* c, const float* pcm, size_t n_samples, double
         const int nb = (int)std::min<size_t>(c->max_batch, nch - base);
         std::vector<int> src(nb, 0), fs(nb), nfs(1, (int)nf);
         for (int i = 0; i < nb; i++) fs[i] = (int)(offs[base + i] / 160);  // frame_start = pos / hop (:895, 950)
+        rc = enc_begin(c);
+        if (rc) return rc;
         CTX_HIP(c, hipMemcpyAsync(c->d_src_index, src.data(), nb * 4, hipMemcpyHostToDevice, s));
         CTX_HIP(c, hipMemcpyAsync(c->d_frame_start, fs.data(), nb * 4, hipMemcpyHostToDevice, s));
         CTX_HIP(c, hipMemcpyAsync(c->d_nframes, nfs.data(), 4, hipMemcpyHostToDevice, s));
@@ -1044,7 +1167,7 @@ int wh_transcribe_longform(wh_ctx* c, const float* pcm, size_t n_samples, double
         if (rc) return rc;
         float a = 0, b = 0;
         hipEventElapsedTime(&a, c->ev[4], c->ev[2]);
-        hipEventElapsedTime(&b, c->ev[2], c->ev[3]);
+        hipEventElapsedTime(&b, c->ev[5], c->ev[3]);
         enc_s += a * 1e-3;
         dec_s += b * 1e-3;
     }

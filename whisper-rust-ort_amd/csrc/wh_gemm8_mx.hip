@@ -358,6 +358,10 @@ bool wh_gemm8_mx_applicable(const GemmArgs& g) {
 
 // out: 0 = bf16, 1 = f32, 2 = MX (codes + exponents in g.c_sc)
 void wh_launch_gemm8_mx(hipStream_t s, int out, const GemmArgs& g) {
+    if (!wh_gemm8_mx_applicable(g)) {   // the geometry guarantees live in one place; callers decide from the context (mx_ok)
+        wh_set_error("k_gemm8_mx: geometry M %d N %d K %d not covered", g.M, g.N, g.K);
+        return;
+    }
     if (out == 2) launch_mx<MxOut>(s, g);
     else if (out == 1) launch_mx<float>(s, g);
     else launch_mx<bf16>(s, g);

@@ -59,7 +59,23 @@ struct wh_model {
 struct wh_ctx {
     wh_model* m = nullptr;
     int max_batch = 1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // cross-K/V projection + token loop (and everything else when s_enc == stream)
+    // log-mel + encoder.  The same stream unless the context was created with wh_ctx_create_ex (CU masks / two streams):
+    // then the next batch's encoder runs beside this batch's token loop, each on its own part of the chip.
+    hipStream_t s_enc = nullptr;
+    hipStream_t cur = nullptr;      // stream of the phase being launched (event brackets of the profiling hooks)
+    // hand-offs between the two streams: encoder states ready (recorded on s_enc), encoder states consumed by the
+    // cross-K/V projection (recorded on stream; the next encoder pass may overwrite them)
+    hipEvent_t ev_enc_done = nullptr, ev_kv_done = nullptr;
+    bool kv_done_armed = false;
+    // stage events of an encoder pass {start, mel done, encoder done}: two sets, because a prefetched pass (the NEXT
+    // batch's) is recorded while the resident pass's times have not been read yet
+    hipEvent_t enc_ev[2][3] = {{nullptr}};
+    int enc_set = 0;                // set of the resident encoder states
+    // encoder states prefetched by wh_transcribe_batch_device_next for its `next` batch
+    const float* pre_pcm = nullptr;
+    int pre_n = 0;
+    bool pre_valid = false;
     std::string err;
     wh_timing timing{};
     bool have_enc = false;  // encoder states of `enc_batch` clips are resident

@@ -10,10 +10,17 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../csrc/wh_json.h"
@@ -433,6 +440,184 @@ inline std::string stitch_texts(const std::vector<std::string>& chunks) {  // :6
         }
     }
     return out;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// the file loop (src/main.rs:1164-1213) as a pipeline: loader threads -> bounded, index-ordered queue -> one worker
+// per context.  The reference loads and transcribes one file after the other and fails fast with the first error;
+// here loading runs ahead of the GPUs, rows stay in file order, and the first error — from a loader or a worker — ends
+// every thread: each path that sets the error or makes a thread leave wakes all three wait points (items, space, pool).
+// ---------------------------------------------------------------------------------------------
+struct PipeItem {
+    size_t idx = 0;
+    std::vector<float> audio;
+    double dur = 0, load_s = 0;
+    float* pin = nullptr;   // samples in a pool buffer instead of `audio`
+    size_t n_pin = 0;
+    size_t n() const { return pin ? n_pin : audio.size(); }
+    const float* data() const { return pin ? pin : audio.data(); }
+};
+
+// Fixed-size staging buffers from caller-supplied alloc / free (page-locked memory in the CLI).  Allocated on first use
+// (only runs that meet a one-window file pay for it) and all or nothing: with a partial pool the loader of the next index
+// in line could wait for a buffer while later, parked indices hold every one of them.
+class BufferPool {
+  public:
+    BufferPool(std::function<float*()> alloc, std::function<void(float*)> dealloc) : alloc_(std::move(alloc)), free_(std::move(dealloc)) {}
+    ~BufferPool() { for (float* p : free_list_) free_(p); }
+    // true if the pool holds `n` buffers (allocating them now if this is the first call); false = use pageable memory
+    bool ensure(size_t n) {
+        std::lock_guard<std::mutex> lk(m_);
+        if (tried_) return total_ > 0;
+        tried_ = true;
+        for (size_t i = 0; i < n; i++) {
+            float* p = alloc_();
+            if (!p) {   // not enough page-locked memory: give back what was taken, run without the pool
+                for (float* q : free_list_) free_(q);
+                free_list_.clear();
+                return false;
+            }
+            free_list_.push_back(p);
+        }
+        total_ = n;
+        return total_ > 0;
+    }
+    float* acquire() {   // nullptr once aborted
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return aborted_ || !free_list_.empty(); });
+        if (aborted_) return nullptr;
+        float* p = free_list_.back();
+        free_list_.pop_back();
+        return p;
+    }
+    void release(float* p) {
+        { std::lock_guard<std::mutex> lk(m_); free_list_.push_back(p); }
+        cv_.notify_one();
+    }
+    void abort() {
+        { std::lock_guard<std::mutex> lk(m_); aborted_ = true; }
+        cv_.notify_all();
+    }
+    size_t total() const { return total_; }
+
+  private:
+    std::function<float*()> alloc_;
+    std::function<void(float*)> free_;
+    std::vector<float*> free_list_;
+    size_t total_ = 0;
+    bool tried_ = false, aborted_ = false;
+    std::mutex m_;
+    std::condition_variable cv_;
+};
+
+// load(idx, audio, dur) fills one file; process(worker, batch) transcribes a batch of one-window files (<= max_batch of
+// them, only what is already loaded) or ONE multi-window file; both may throw.  Returns the first error ("" = none).
+// `pool` (optional) stages one-window files; its buffers go back to the pool after process() returns.
+inline std::string run_file_pipeline(size_t nfiles, int n_loaders, size_t n_workers, size_t max_batch, size_t window_samples, BufferPool* pool,
+                                     const std::function<void(size_t, std::vector<float>&, double&)>& load,
+                                     const std::function<void(size_t, std::vector<PipeItem>&)>& process) {
+    std::mutex mu;
+    std::condition_variable cv_items, cv_space;
+    std::deque<PipeItem> ready;               // loaded files, in index order
+    std::map<size_t, PipeItem> parked;        // loaded out of order, waiting for their turn
+    size_t next_ready = 0;                    // index the queue is waiting for
+    size_t handed = 0;                        // files handed to workers so far (under mu)
+    std::atomic<size_t> next_load{0};
+    std::string first_error;
+    const size_t cap = max_batch * n_workers * 2 + 4;                         // look-ahead of the loaders
+    const size_t pool_size = cap + max_batch * n_workers + (size_t)n_loaders;   // look-ahead + batches in flight + one per loader
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto fail = [&](const std::string& what) {   // call WITHOUT mu held
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (first_error.empty()) first_error = what.empty() ? "unknown error" : what;
+        }
+        cv_items.notify_all();
+        cv_space.notify_all();
+        if (pool) pool->abort();
+    };
+    auto loader = [&]() {
+        for (;;) {
+            const size_t i = next_load.fetch_add(1);
+            if (i >= nfiles) return;
+            { std::lock_guard<std::mutex> lk(mu); if (!first_error.empty()) return; }
+            PipeItem it;
+            it.idx = i;
+            try {
+                const double tl0 = now();
+                load(i, it.audio, it.dur);
+                it.load_s = now() - tl0;
+                // one-window files move into a staging buffer of the pool (page-locked in the CLI: the library's host-to-device
+                // copy is then one DMA at link speed; a pageable source goes through the runtime's staging buffers)
+                if (pool && it.audio.size() <= window_samples && pool->ensure(pool_size)) {
+                    it.pin = pool->acquire();
+                    if (!it.pin) return;   // aborted: another thread has failed
+                    memcpy(it.pin, it.audio.data(), it.audio.size() * sizeof(float));
+                    it.n_pin = it.audio.size();
+                    std::vector<float>().swap(it.audio);
+                }
+            } catch (const std::exception& e) {
+                fail(e.what());
+                return;
+            }
+            std::unique_lock<std::mutex> lk(mu);
+            cv_space.wait(lk, [&] { return !first_error.empty() || i < handed + cap; });   // bounded look-ahead of the consumers
+            if (!first_error.empty()) {
+                if (it.pin) pool->release(it.pin);
+                return;
+            }
+            parked.emplace(i, std::move(it));
+            while (!parked.empty() && parked.begin()->first == next_ready) {
+                ready.push_back(std::move(parked.begin()->second));
+                parked.erase(parked.begin());
+                next_ready++;
+            }
+            cv_items.notify_all();
+        }
+    };
+    auto worker = [&](size_t wi) {
+        for (;;) {
+            std::vector<PipeItem> batch;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                // wait for a full batch, the end of the input, or a multi-window file at the front (it goes alone)
+                cv_items.wait(lk, [&] {
+                    return !first_error.empty() || handed == nfiles || ready.size() >= max_batch || handed + ready.size() == nfiles ||
+                           (!ready.empty() && ready.front().n() > window_samples);
+                });
+                if (!first_error.empty() || ready.empty()) {
+                    if (!first_error.empty() || handed == nfiles) return;
+                    continue;
+                }
+                if (ready.front().n() > window_samples) {
+                    batch.push_back(std::move(ready.front()));
+                    ready.pop_front();
+                } else {
+                    while (!ready.empty() && batch.size() < max_batch && ready.front().n() <= window_samples) {
+                        batch.push_back(std::move(ready.front()));
+                        ready.pop_front();
+                    }
+                }
+                handed += batch.size();
+            }
+            cv_space.notify_all();
+            cv_items.notify_all();
+            try {
+                process(wi, batch);
+                for (PipeItem& it : batch)
+                    if (it.pin) pool->release(it.pin);
+            } catch (const std::exception& e) {
+                fail(e.what());
+                return;
+            }
+        }
+    };
+    std::vector<std::thread> threads;
+    for (int i = 0; i < n_loaders; i++) threads.emplace_back(loader);
+    for (size_t wi = 0; wi < n_workers; wi++) threads.emplace_back(worker, wi);
+    for (auto& t : threads) t.join();
+    return first_error;
 }
 
 }  // namespace whhost

@@ -78,4 +78,46 @@ int whh_load_wav(const char* path, float* out, size_t cap, size_t* n, double* du
         return 0;
     } catch (...) { return 1; }
 }
+// The CLI's loader / worker pipeline (run_file_pipeline) with stand-in load and process callbacks: file `bad_load` fails to
+// load, the batch holding file `bad_process` fails in the worker (either may be >= nfiles: none), `pool_buffers` staging
+// buffers can be allocated before the allocator runs dry (0 = no pool).  Returns 0 and the number of processed files, or 1
+// and the error text; a deadlock would simply never return — the test runs it under a timeout.
+int whh_pipeline_selftest(size_t nfiles, int n_loaders, size_t n_workers, size_t max_batch, size_t bad_load, size_t bad_process,
+                          size_t pool_buffers, size_t long_every, size_t* n_processed, char* err, size_t cap) {
+    const size_t window = 64;
+    std::atomic<size_t> allocated{0}, done{0};
+    std::vector<int> seen(nfiles, 0);
+    std::mutex sm;
+    BufferPool pool([&]() -> float* { return allocated.fetch_add(1) < pool_buffers ? (float*)malloc(window * sizeof(float)) : nullptr; },
+                    [](float* p) { free(p); });
+    auto load = [&](size_t i, std::vector<float>& audio, double& dur) {
+        if (i == bad_load) throw std::runtime_error("cannot decode file " + std::to_string(i));
+        const bool is_long = long_every && (i % long_every) == long_every - 1;
+        audio.assign(is_long ? 3 * window : window - (i % 5), (float)i);
+        dur = (double)audio.size();
+        std::this_thread::sleep_for(std::chrono::microseconds(200 + 37 * (i % 7)));
+    };
+    auto process = [&](size_t, std::vector<PipeItem>& batch) {
+        if (batch.empty() || batch.size() > max_batch) throw std::runtime_error("bad batch size");
+        if (batch.size() > 1)
+            for (auto& it : batch)
+                if (it.n() > window) throw std::runtime_error("a multi-window file must go alone");
+        for (size_t k = 0; k < batch.size(); k++) {
+            if (k && batch[k].idx != batch[k - 1].idx + 1) throw std::runtime_error("batch not in file order");
+            if (batch[k].idx == bad_process) throw std::runtime_error("transcribe failed for file " + std::to_string(batch[k].idx));
+            if (batch[k].data()[0] != (float)batch[k].idx) throw std::runtime_error("payload mismatch");
+            std::lock_guard<std::mutex> lk(sm);
+            seen[batch[k].idx]++;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(500));
+        done += batch.size();
+    };
+    const std::string e = run_file_pipeline(nfiles, n_loaders, n_workers, max_batch, window, pool_buffers ? &pool : nullptr, load, process);
+    if (n_processed) *n_processed = done.load();
+    put(e, err, cap);
+    if (!e.empty()) return 1;
+    for (size_t i = 0; i < nfiles; i++)
+        if (seen[i] != 1) { put("file " + std::to_string(i) + " processed " + std::to_string(seen[i]) + " times", err, cap); return 2; }
+    return 0;
+}
 }

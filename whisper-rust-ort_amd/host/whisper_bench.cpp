@@ -379,175 +379,70 @@ int main(int argc, char** argv) {
                 for (size_t i = 0; i < a.warmup; i++) { Timing t; transcribe(c, a0, a, &tok, gen, t); }
         }
 
-        // ---- the file loop (:1164-1213) as a pipeline: loader threads -> bounded queue -> one worker per context ----
-        struct Item {
-            size_t idx; std::vector<float> audio; double dur = 0, load_s = 0;
-            float* pin = nullptr; size_t n_pin = 0;                       // samples in a pool buffer instead of `audio`
-            size_t n() const { return pin ? n_pin : audio.size(); }
-            const float* data() const { return pin ? pin : audio.data(); }
-        };
-        struct PinnedPool {   // page-locked 30 s buffers, allocated once
-            std::vector<float*> free_list; size_t total = 0;
-            std::mutex m; std::condition_variable cv;
-            bool empty_pool() const { return total == 0; }
-            void init(size_t n) {
-                for (size_t i = 0; i < n; i++) {
-                    float* p = nullptr;
-                    if (hipHostMalloc((void**)&p, (size_t)WH_CLIP_SAMPLES * sizeof(float), hipHostMallocDefault) != hipSuccess) break;
-                    free_list.push_back(p);
-                }
-                total = free_list.size();
-            }
-            float* acquire() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return !free_list.empty(); }); float* p = free_list.back(); free_list.pop_back(); return p; }
-            void release(float* p) { { std::lock_guard<std::mutex> lk(m); free_list.push_back(p); } cv.notify_one(); }
-            ~PinnedPool() { for (float* p : free_list) (void)hipHostFree(p); }
-        } pool;
+        // ---- the file loop (:1164-1213) as a pipeline (wh_host.h run_file_pipeline): loader threads -> bounded queue -> one
+        // worker per context; one-window files are staged in page-locked buffers ----
+        typedef PipeItem Item;
+        BufferPool pool([]() -> float* {
+                            float* p = nullptr;
+                            return hipHostMalloc((void**)&p, (size_t)WH_CLIP_SAMPLES * sizeof(float), hipHostMallocDefault) == hipSuccess ? p : nullptr;
+                        },
+                        [](float* p) { (void)hipHostFree(p); });
         struct Result { std::string text; double dur = 0, load_s = 0; Timing t; bool ok = false; };
         const size_t nfiles = files.size();
         std::vector<Result> results(nfiles);
-        std::mutex mu;
-        std::condition_variable cv_items, cv_space;
-        std::deque<Item> ready;                   // loaded files, in index order
-        std::map<size_t, Item> parked;            // loaded out of order, waiting for their turn
-        size_t next_ready = 0;                    // index the queue is waiting for
-        size_t handed = 0;                        // files handed to workers so far (under mu)
-        std::atomic<size_t> next_load{0};
-        std::string first_error;
-        const size_t cap = (size_t)a.max_batch * ctxs.size() * 2 + 4;
         const unsigned hc = std::thread::hardware_concurrency();
         const int n_loaders = a.load_threads > 0 ? a.load_threads : (int)std::min<unsigned>(8, std::max<unsigned>(1, hc / 2));
-        pool.init(cap + (size_t)a.max_batch * ctxs.size() + (size_t)n_loaders);   // look-ahead + batches in flight + one per loader
-        auto loader = [&]() {
-            for (;;) {
-                const size_t i = next_load.fetch_add(1);
-                if (i >= nfiles) return;
-                Item it;
-                it.idx = i;
-                try {
-                    const double tl0 = now_s();
-                    load(i, it.audio, it.dur);
-                    it.load_s = now_s() - tl0;
-                    // one-window files move into a page-locked buffer of the pool, so the library's host-to-device copy is one
-                    // DMA at link speed (a pageable source goes through the runtime's staging buffers: 123 MB per 64-clip batch
-                    // cost 5 ms of a 70 ms batch); the pool is sized to the look-ahead, a loader waits for a free buffer
-                    if (it.audio.size() <= (size_t)WH_CLIP_SAMPLES && !pool.empty_pool()) {
-                        it.pin = pool.acquire();
-                        if (it.pin) {
-                            memcpy(it.pin, it.audio.data(), it.audio.size() * sizeof(float));
-                            it.n_pin = it.audio.size();
-                            std::vector<float>().swap(it.audio);
-                        }
-                    }
-                } catch (const std::exception& e) {
-                    std::lock_guard<std::mutex> lk(mu);
-                    if (first_error.empty()) first_error = e.what();
-                    cv_items.notify_all();
-                    return;
-                }
-                std::unique_lock<std::mutex> lk(mu);
-                cv_space.wait(lk, [&] { return !first_error.empty() || i < handed + cap; });   // bounded look-ahead of the consumers
-                if (!first_error.empty()) return;
-                parked.emplace(i, std::move(it));
-                while (!parked.empty() && parked.begin()->first == next_ready) {
-                    ready.push_back(std::move(parked.begin()->second));
-                    parked.erase(parked.begin());
-                    next_ready++;
-                }
-                cv_items.notify_all();
-            }
-        };
         WhisperSpecial sp = special_tokens(a.language, a.task, &tok);
         std::vector<int64_t> prompt = {sp.sot, sp.lang, sp.task};
         if (!a.timestamps) prompt.push_back(sp.no_timestamps);
         std::vector<double> busy_s(ctxs.size(), 0.0);
-        auto worker = [&](size_t wi) {
+        auto process = [&](size_t wi, std::vector<Item>& batch) {
             wh_ctx* ctx = ctxs[wi];
             const size_t stride = prompt.size() + a.max_new_tokens;
-            std::vector<int64_t> toks((size_t)a.max_batch * stride);
-            std::vector<size_t> ntok(a.max_batch);
-            for (;;) {
-                std::vector<Item> batch;
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    // wait for a full batch, the end of the input, or a multi-window file at the front (it goes alone)
-                    cv_items.wait(lk, [&] {
-                        return !first_error.empty() || handed == nfiles || (int)ready.size() >= a.max_batch || handed + ready.size() == nfiles ||
-                               (!ready.empty() && ready.front().n() > (size_t)WH_CLIP_SAMPLES);
-                    });
-                    if (!first_error.empty() || ready.empty()) {
-                        if (!first_error.empty() || handed == nfiles) return;
-                        continue;
-                    }
-                    // a file longer than one window goes alone through the long-form entry (which batches its windows);
-                    // single-window files are batched together, at most max_batch, only what is already loaded
-                    if (ready.front().n() > (size_t)WH_CLIP_SAMPLES) {
-                        batch.push_back(std::move(ready.front()));
-                        ready.pop_front();
-                    } else {
-                        while (!ready.empty() && (int)batch.size() < a.max_batch && ready.front().n() <= (size_t)WH_CLIP_SAMPLES) {
-                            batch.push_back(std::move(ready.front()));
-                            ready.pop_front();
-                        }
-                    }
-                    handed += batch.size();
-                    cv_space.notify_all();
-                    if (handed == nfiles) cv_items.notify_all();
-                }
-                try {
-                    const double tb0 = now_s();
-                    if (batch.size() == 1 && batch[0].n() > (size_t)WH_CLIP_SAMPLES) {
-                        Result& r = results[batch[0].idx];
-                        r.text = transcribe(ctx, batch[0].audio, a, &tok, gen, r.t);
-                        r.dur = batch[0].dur; r.load_s = batch[0].load_s; r.ok = true;
-                    } else {
-                        // the per-window body of transcribe_longform_chunked (:870-915) for a batch of one-window files
-                        wh_decode_params p{};
-                        p.prompt = prompt.data(); p.n_prompt = prompt.size(); p.max_new_tokens = a.max_new_tokens; p.eot = sp.eot;
-                        p.suppress = gen.suppress.data(); p.n_suppress = gen.suppress.size();
-                        p.begin_suppress = gen.begin_suppress.data(); p.n_begin_suppress = gen.begin_suppress.size();
-                        std::vector<wh_clip> clips(batch.size());
-                        for (size_t k = 0; k < batch.size(); k++) { clips[k].pcm = batch[k].data(); clips[k].n_samples = batch[k].n(); }
-                        const double t0 = now_s();
-                        int rc = wh_transcribe_batch(ctx, clips.data(), clips.size(), &p, toks.data(), ntok.data());
-                        if (rc) throw std::runtime_error(std::string("libwhisper_hip error ") + std::to_string(rc) + ": " + wh_last_error(ctx));
-                        const double batch_s = now_s() - t0;
-                        wh_timing wt{};
-                        wh_get_timings(ctx, &wt);
-                        for (size_t k = 0; k < batch.size(); k++) {   // :926-943
-                            Result& r = results[batch[k].idx];
-                            const double td0 = now_s();
-                            std::vector<int64_t> g;
-                            if (ntok[k] > prompt.size()) g.assign(toks.begin() + k * stride + prompt.size(), toks.begin() + k * stride + ntok[k]);
-                            if (!g.empty() && g.back() == sp.eot) g.pop_back();
-                            std::string text = decode_tokens(g, &tok);
-                            if (text.empty()) text = "[EMPTY]";
-                            std::vector<std::string> texts;
-                            if (text != "[EMPTY]") texts.push_back(text);
-                            r.text = stitch_texts(texts);
-                            r.t.preprocess_s = wt.preprocess_s;
-                            r.t.model_only_s = wt.encode_s + wt.decode_s;
-                            r.t.decode_s = now_s() - td0;
-                            r.t.end_to_end_s = batch_s + r.t.decode_s;   // every clip of a batch completes with its batch
-                            r.dur = batch[k].dur; r.load_s = batch[k].load_s; r.ok = true;
-                        }
-                    }
-                    busy_s[wi] += now_s() - tb0;
-                    for (Item& it : batch)
-                        if (it.pin) pool.release(it.pin);
-                } catch (const std::exception& e) {
-                    std::lock_guard<std::mutex> lk(mu);
-                    if (first_error.empty()) first_error = e.what();
-                    cv_items.notify_all();
-                    cv_space.notify_all();
-                    return;
+            const double tb0 = now_s();
+            if (batch.size() == 1 && batch[0].n() > (size_t)WH_CLIP_SAMPLES) {
+                // a file longer than one window goes alone through the long-form entry (which batches its windows)
+                Result& r = results[batch[0].idx];
+                r.text = transcribe(ctx, batch[0].audio, a, &tok, gen, r.t);
+                r.dur = batch[0].dur; r.load_s = batch[0].load_s; r.ok = true;
+            } else {
+                // the per-window body of transcribe_longform_chunked (:870-915) for a batch of one-window files
+                std::vector<int64_t> toks(batch.size() * stride);
+                std::vector<size_t> ntok(batch.size());
+                wh_decode_params p{};
+                p.prompt = prompt.data(); p.n_prompt = prompt.size(); p.max_new_tokens = a.max_new_tokens; p.eot = sp.eot;
+                p.suppress = gen.suppress.data(); p.n_suppress = gen.suppress.size();
+                p.begin_suppress = gen.begin_suppress.data(); p.n_begin_suppress = gen.begin_suppress.size();
+                std::vector<wh_clip> clips(batch.size());
+                for (size_t k = 0; k < batch.size(); k++) { clips[k].pcm = batch[k].data(); clips[k].n_samples = batch[k].n(); }
+                const double t0 = now_s();
+                int rc = wh_transcribe_batch(ctx, clips.data(), clips.size(), &p, toks.data(), ntok.data());
+                if (rc) throw std::runtime_error(std::string("libwhisper_hip error ") + std::to_string(rc) + ": " + wh_last_error(ctx));
+                const double batch_s = now_s() - t0;
+                wh_timing wt{};
+                wh_get_timings(ctx, &wt);
+                for (size_t k = 0; k < batch.size(); k++) {   // :926-943
+                    Result& r = results[batch[k].idx];
+                    const double td0 = now_s();
+                    std::vector<int64_t> g;
+                    if (ntok[k] > prompt.size()) g.assign(toks.begin() + k * stride + prompt.size(), toks.begin() + k * stride + ntok[k]);
+                    if (!g.empty() && g.back() == sp.eot) g.pop_back();
+                    std::string text = decode_tokens(g, &tok);
+                    if (text.empty()) text = "[EMPTY]";
+                    std::vector<std::string> texts;
+                    if (text != "[EMPTY]") texts.push_back(text);
+                    r.text = stitch_texts(texts);
+                    r.t.preprocess_s = wt.preprocess_s;
+                    r.t.model_only_s = wt.encode_s + wt.decode_s;
+                    r.t.decode_s = now_s() - td0;
+                    r.t.end_to_end_s = batch_s + r.t.decode_s;   // every clip of a batch completes with its batch
+                    r.dur = batch[k].dur; r.load_s = batch[k].load_s; r.ok = true;
                 }
             }
+            busy_s[wi] += now_s() - tb0;
         };
         const double loop0 = now_s();
-        std::vector<std::thread> threads;
-        for (int i = 0; i < n_loaders; i++) threads.emplace_back(loader);
-        for (size_t wi = 0; wi < ctxs.size(); wi++) threads.emplace_back(worker, wi);
-        for (auto& t : threads) t.join();
+        const std::string first_error = run_file_pipeline(nfiles, n_loaders, ctxs.size(), (size_t)a.max_batch, (size_t)WH_CLIP_SAMPLES, &pool, load, process);
         const double loop_s = now_s() - loop0;
         if (!first_error.empty()) throw std::runtime_error(first_error);
 
