@@ -76,7 +76,10 @@ static std::vector<uint32_t> mask_range(int first, int count) {
 
 static hipStream_t masked_stream(const std::vector<uint32_t>& m) {
     hipStream_t s;
-    CK(hipExtStreamCreateWithCUMask(&s, (uint32_t)m.size(), m.data()));
+    size_t bits = 0;
+    for (uint32_t w : m) bits += (size_t)__builtin_popcount(w);
+    if (bits >= 256) CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));   // the whole chip: no mask
+    else CK(hipExtStreamCreateWithCUMask(&s, (uint32_t)m.size(), m.data()));
     return s;
 }
 
@@ -93,8 +96,10 @@ int main() {
     struct Case { const char* name; int first, count; };
     const Case cases[] = {{"bits 0..7", 0, 8},     {"bits 0..15", 0, 16},   {"bits 0..31", 0, 32},    {"bits 0..63", 0, 64},
                           {"bits 0..127", 0, 128}, {"bits 64..255", 64, 192}, {"bits 96..255", 96, 160}, {"bits 128..255", 128, 128},
-                          {"bits 8..15", 8, 8},    {"bit 0", 0, 1},          {"bit 1", 1, 1},           {"bit 8", 8, 1},
-                          {"bits 0..255", 0, 256}};
+                          {"bits 8..15", 8, 8},    {"bit 0", 0, 1},          {"bit 1", 1, 1},           {"bit 8", 8, 1}};
+    // (a mask with all 256 bits set never got past this point on the test box — the run was killed by its time limit; the
+    // library turns such a mask into an ordinary stream.  An XCD whose 32 bits are all clear is not restricted at all: "bit 0"
+    // alone selects one compute unit of XCD 0 and every compute unit of the other seven.)
     for (const Case& cs : cases) {
         hipStream_t s = masked_stream(mask_range(cs.first, cs.count));
         CK(hipMemsetAsync(d_where, 0xFF, NWG * 8, s));

@@ -498,6 +498,8 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
         } else {
             launch_step(true, false);
         }
+        // diagnostic (profiles/README.md, rocprofv3 --pmc at whisper-large-v3 size): bound the number of dispatches in flight
+        if (c->sync_every_pos) hipStreamSynchronize(s);
         // EOT early-out (src/main.rs:781-783, 820-822): poll the done flags every 16 generated tokens
         const int gen = r + 1;
         if ((gen & 15) == 15 && r + 1 < remaining && p->n_forced == 0) {
@@ -702,11 +704,25 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
         wh_set_error("wh_ctx_create_ex: a CU mask with no bit set would leave its stream without compute units");
         return WH_ERR_ARG;
     }
+    // A mask must restrict every XCD it is meant to restrict: bit i is compute unit i / 8 of XCD i % 8, and an XCD none of
+    // whose bits is set is not restricted at all (measured, tools/cu_mask_probe.hip) — refuse such a mask instead of silently
+    // running on compute units the caller meant to leave to the other stream.  A mask naming every compute unit is no mask.
     WH_HIP_CHECK(hipSetDevice(m->device));
+    int n_cus = 0;
+    WH_HIP_CHECK(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, m->device));
+    auto xcds_covered = [](const uint32_t* w, size_t n) { unsigned seen = 0; for (size_t i = 0; i < n * 32; i++) if (w[i >> 5] >> (i & 31) & 1) seen |= 1u << (i & 7); return seen == 0xFFu; };
+    if ((opts->enc_cu_mask_words && !xcds_covered(opts->enc_cu_mask, opts->enc_cu_mask_words)) ||
+        (opts->dec_cu_mask_words && !xcds_covered(opts->dec_cu_mask, opts->dec_cu_mask_words))) {
+        wh_set_error("wh_ctx_create_ex: a CU mask must select at least one compute unit of every XCD (bit i = compute unit i / 8 of XCD i %% 8)");
+        return WH_ERR_ARG;
+    }
+    const bool enc_masked = opts->enc_cu_mask_words && (int)mask_bits(opts->enc_cu_mask, opts->enc_cu_mask_words) < n_cus;
+    const bool dec_masked = opts->dec_cu_mask_words && (int)mask_bits(opts->dec_cu_mask, opts->dec_cu_mask_words) < n_cus;
     auto* c = new wh_ctx();
     c->m = m;
     c->max_batch = max_batch;
     c->no_graph = getenv("WH_NO_GRAPH") != nullptr;
+    c->sync_every_pos = getenv("WH_SYNC_EVERY_POS") != nullptr;
     const wh_dims& D = m->dims;
     const size_t B = max_batch, d = D.d_model, S = D.n_audio_ctx, F = D.ffn, C = D.n_mels, esz = m->esz;
     const size_t Ld = D.dec_layers, H = D.n_heads, TC = D.n_text_ctx;
@@ -774,12 +790,12 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     // streams: one for everything, or — chip partition — the token loop on `stream` and log-mel + encoder on `s_enc`, each
     // optionally confined to a set of compute units (hipExtStreamCreateWithCUMask: bit i of the mask is compute unit
     // i / 8 of XCD i % 8 on this part, tools/cu_mask_probe.hip)
-    if (opts->dec_cu_mask_words) he = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)opts->dec_cu_mask_words, opts->dec_cu_mask);
+    if (dec_masked) he = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)opts->dec_cu_mask_words, opts->dec_cu_mask);
     else he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (he != hipSuccess) { hipFree(c->ws); delete c; return wh_fail_hip(he, "hipStreamCreate", __FILE__, __LINE__); }
     c->s_enc = c->stream;
     if (opts->enc_cu_mask_words || (opts->flags & WH_CTX_TWO_STREAMS)) {
-        if (opts->enc_cu_mask_words) he = hipExtStreamCreateWithCUMask(&c->s_enc, (uint32_t)opts->enc_cu_mask_words, opts->enc_cu_mask);
+        if (enc_masked) he = hipExtStreamCreateWithCUMask(&c->s_enc, (uint32_t)opts->enc_cu_mask_words, opts->enc_cu_mask);
         else he = hipStreamCreateWithFlags(&c->s_enc, hipStreamNonBlocking);
         if (he != hipSuccess) { hipStreamDestroy(c->stream); hipFree(c->ws); delete c; return wh_fail_hip(he, "hipStreamCreate(encoder stream)", __FILE__, __LINE__); }
     }

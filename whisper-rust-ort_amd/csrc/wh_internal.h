@@ -86,6 +86,7 @@ struct wh_ctx {
     int prof_stride = 0;     // > 1: only every stride-th generated position is launched eagerly with events
     bool capturing = false;  // a decode step is being captured into a hipGraph
     bool no_graph = false;  // WH_NO_GRAPH=1: launch every decode step eagerly
+    bool sync_every_pos = false;  // WH_SYNC_EVERY_POS=1: host waits after every decoder position (profiler triage only)
     int prof_group = -1;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[WH_KG_COUNT];
     size_t prof_used[WH_KG_COUNT] = {0};
