@@ -128,9 +128,10 @@ def window_mel(mel_full: np.ndarray, frame_start: int, win_frames: int = 3000) -
 
 
 def mx_applies(dims) -> bool:
-    """The build's fp8 mode uses MX activations (fp8 MFMA) when every contraction length is 256 / 512 / 1024 / 2048."""
-    ok = (256, 512, 1024, 2048)
-    return dims.d_model in ok and dims.ffn in ok
+    """The build's fp8 mode uses MX activations (fp8 MFMA) when every contraction length is a multiple of 128 from 256 on and
+    d_model is a width its MX LayerNorm exists for (whisper-rust-ort_amd/csrc/wh_kernels.h: wh_mx_ln_width)."""
+    return (dims.d_model in (256, 512, 1024, 1280, 1536, 2048) and dims.ffn >= 256 and dims.ffn % 128 == 0
+            and dims.n_audio_ctx >= 256)
 
 
 def encoder(dims, wflat: np.ndarray, mel: np.ndarray, act_mx: bool = False) -> np.ndarray:

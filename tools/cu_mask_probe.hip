@@ -84,6 +84,7 @@ static hipStream_t masked_stream(const std::vector<uint32_t>& m) {
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);   // a run that is killed at its time limit still shows how far it got
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     printf("device: %s, %d CUs\n", prop.name, prop.multiProcessorCount);

@@ -168,7 +168,7 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
             g.W = c->xn; g.ldw = d; g.w_zs = S * d;
             g.C = c->vT; g.ldc = c->ldv; g.c_zs = d * c->ldv;
             g.bias = L.v_b; g.bias_mode = 2; g.wscale = L.v_sc; g.M = (int)d; g.N = (int)S; g.K = (int)d; g.batch = nb;
-            if (mx && d >= 256) { g.A = L.v_w8; g.W = c->xn8; g.w_sc8 = c->xn8_sc; g.w_sc_zs = S * d / 32; wh_launch_gemm8_mx(s, 0, g); }
+            if (mx && d >= 256) { g.A = L.v_w8; g.W = c->xn8; g.w_sc8 = c->xn8_sc; g.w_sc_zs = S * 4 * wh_mx_nkp((int)d); wh_launch_gemm8_mx(s, 0, g); }
             else if (mx) return fail(c, WH_ERR_UNSUPPORTED, "MX activations need d_model >= 256");
             else wh_launch_gemm(s, prec, false, g);
         }
@@ -748,10 +748,11 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     const size_t o_ckv8 = f8 ? cv.take(Ld * 2 * B * S * d) : 0, o_kvam = f8 ? cv.take(Ld * 2 * B * H * 4) : 0;
     // fp8-MFMA encoder (wh_gemm8_mx.hip): MX activations when every contraction length is one the kernel takes
     // (decided from the model and the context only, never from a call's clip count: S >= 256 rows is one full tile even for one clip)
-    auto mx_k = [](size_t k) { return k == 256 || k == 512 || k == 1024 || k == 2048; };
-    c->mx_ok = f8 && mx_k(d) && mx_k(F) && (d % 256) == 0 && S >= 256 && getenv("WH_NO_MX") == nullptr;
-    const size_t o_xn8 = c->mx_ok ? cv.take(B * S * d) : 0, o_xn8s = c->mx_ok ? cv.take(B * S * d / 32) : 0;
-    const size_t o_h8 = c->mx_ok ? cv.take(B * S * F) : 0, o_h8s = c->mx_ok ? cv.take(B * S * F / 32) : 0;
+    // contraction lengths: any multiple of 128 from 256 on (whisper-large-v3: 1280, 5120); d_model must be a width k_layernorm_mx exists for
+    auto mx_k = [](size_t k) { return k >= 256 && (k % 128) == 0; };
+    c->mx_ok = f8 && mx_k(d) && mx_k(F) && wh_mx_ln_width((int)d) && S >= 256 && getenv("WH_NO_MX") == nullptr;
+    const size_t o_xn8 = c->mx_ok ? cv.take(B * S * d) : 0, o_xn8s = c->mx_ok ? cv.take(B * S * 4 * wh_mx_nkp((int)d)) : 0;
+    const size_t o_h8 = c->mx_ok ? cv.take(B * S * F) : 0, o_h8s = c->mx_ok ? cv.take(B * S * 4 * wh_mx_nkp((int)F)) : 0;
     const size_t o_sk = cv.take(Ld * B * H * TC * WH_HEAD_DIM * esz), o_sv = cv.take(Ld * B * H * TC * WH_HEAD_DIM * esz);
     const size_t MP = (size_t)c->mpad;  // slab-layout activations: [K/32][MP][32]
     const size_t o_dx = cv.take(B * d * 4), o_dxn = cv.take(MP * d * esz), o_dqkv = cv.take(B * 3 * d * esz);

@@ -19,8 +19,11 @@
 // A [256][128 B] + W [128][128 B] = 48 KiB, three slots, LDS-DMA with the bank swizzle on the source side
 // (chunk p of row r holds k-chunk p ^ ((r >> 1) & 7): conflict-free for the chunk pairs (g, 4 + g)), counted vmcnt, one
 // barrier per K-step, wave-private LDS staging of the output, 16-byte row-contiguous stores.  Block exponents are laid
-// out [row][4][K/128] so that a lane's bytes for consecutive K-steps are adjacent: all of a tile's exponents are loaded
-// once, before the ring starts (no ordinary load shares the loop with the LDS-DMA).
+// out [row][4][nkp] (nkp = K/128 rounded up to a multiple of 4 from 4 on: wh_mx_nkp) so that a lane's bytes for consecutive
+// K-steps are adjacent dwords: the exponents of 16 K-steps (a segment) sit in four registers per tile row, loaded before the
+// ring starts.  Contractions longer than 16 K-steps (whisper-large-v3's ffn 5120: 40) reload them at each segment's end,
+// behind that step's MFMAs, and the next step waits for vmcnt(0) once — the only ordinary loads that share the loop with the
+// LDS-DMA, one partial drain per 16 K-steps.
 #include <type_traits>
 
 #include "wh_common.h"
@@ -34,7 +37,7 @@ constexpr int SLOT_A = BM * ROWB, SLOT = SLOT_A + BN * ROWB;   // 32 + 16 KiB
 constexpr int NSLOT = 3, PER_STAGE = 6;
 constexpr int TM = 4, TN = 4;
 constexpr int EP_PITCH = 68, EP_ROWS = 32;
-constexpr int MAX_NK = 16;                                     // K <= 2048
+constexpr int MAX_NK = 16;                                     // K-steps per exponent segment (four dwords per tile row)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -47,16 +50,16 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// the exponents of one row, lane group fg, K-steps 0 .. nk-1 (nk in {2, 4, 8, 16}) as up to four dwords
-__device__ __forceinline__ void load_exps(const unsigned char* base, long row, int fg, int nk, unsigned (&dw)[MAX_NK / 4]) {
-    const unsigned char* p = base + (row * 4 + fg) * nk;
+// the exponents of one row, lane group fg, K-steps 16 seg .. 16 seg + 15 as up to four dwords (row pitch 4 * nkp bytes)
+__device__ __forceinline__ void load_exps(const unsigned char* base, long row, int fg, int nkp, int seg, unsigned (&dw)[MAX_NK / 4]) {
+    const unsigned char* p = base + (row * 4 + fg) * nkp + seg * MAX_NK;
 #pragma unroll
     for (int i = 0; i < MAX_NK / 4; i++) dw[i] = 0x7F7F7F7Fu;
-    if (nk == 2) dw[0] = *reinterpret_cast<const unsigned short*>(p) | 0x7F7F0000u;
+    if (nkp == 2) dw[0] = *reinterpret_cast<const unsigned short*>(p) | 0x7F7F0000u;
     else {
 #pragma unroll
         for (int i = 0; i < MAX_NK / 4; i++)
-            if (4 * i < nk) dw[i] = *reinterpret_cast<const unsigned*>(p + 4 * i);
+            if (seg * MAX_NK + 4 * i < nkp) dw[i] = *reinterpret_cast<const unsigned*>(p + 4 * i);
     }
 }
 
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8_mx(GemmArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int fl = lane & 15, fg = lane >> 4;
-    const int nk = g.K / BKB;
+    const int nk = g.K / BKB, nkp = wh_mx_nkp(g.K);
 
     const int nbn = (g.N + BN - 1) / BN;
     const int total = nbn * ((g.M + BM - 1) / BM);
@@ -91,20 +94,24 @@ __global__ __launch_bounds__(512, 2) void k_gemm8_mx(GemmArgs g) {
     const unsigned char* W = (const unsigned char*)g.W + z * g.w_zs;
     const int mw0 = m0 + wm * 64, nw0 = n0 + wn * 64;
 
-    // block exponents of this wave's rows: before anything else, and complete before the ring starts
+    // block exponents of this wave's rows, one segment of 16 K-steps at a time: the first before anything else, complete
+    // before the ring starts
     unsigned ea[TM][MAX_NK / 4], ew[TN][MAX_NK / 4];
+    auto load_segment = [&](int seg) {
 #pragma unroll
-    for (int i = 0; i < TM; i++) {
+        for (int i = 0; i < TM; i++) {
 #pragma unroll
-        for (int q = 0; q < MAX_NK / 4; q++) ea[i][q] = 0x7F7F7F7Fu;
-        if (g.a_sc) load_exps(g.a_sc + z * g.a_sc_zs, min(mw0 + i * 16 + fl, g.M - 1), fg, nk, ea[i]);
-    }
+            for (int q = 0; q < MAX_NK / 4; q++) ea[i][q] = 0x7F7F7F7Fu;
+            if (g.a_sc) load_exps(g.a_sc + z * g.a_sc_zs, min(mw0 + i * 16 + fl, g.M - 1), fg, nkp, seg, ea[i]);
+        }
 #pragma unroll
-    for (int j = 0; j < TN; j++) {
+        for (int j = 0; j < TN; j++) {
 #pragma unroll
-        for (int q = 0; q < MAX_NK / 4; q++) ew[j][q] = 0x7F7F7F7Fu;
-        if (g.w_sc8) load_exps(g.w_sc8 + z * g.w_sc_zs, min(nw0 + j * 16 + fl, g.N - 1), fg, nk, ew[j]);
-    }
+            for (int q = 0; q < MAX_NK / 4; q++) ew[j][q] = 0x7F7F7F7Fu;
+            if (g.w_sc8) load_exps(g.w_sc8 + z * g.w_sc_zs, min(nw0 + j * 16 + fl, g.N - 1), fg, nkp, seg, ew[j]);
+        }
+    };
+    load_segment(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // per-lane source pointers of this wave's share of a stage: one wave-instruction = 1 KiB = 8 rows x 128 bytes
@@ -143,7 +150,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm8_mx(GemmArgs g) {
     stage(0, 0);
     if (nk > 1) stage(1, 1);
     for (int kt = 0; kt < nk; kt++) {
-        if (kt + 1 < nk) wait_vm<PER_STAGE>();
+        // (first step of a later segment: the exponent loads issued behind the previous step's MFMAs are the youngest requests)
+        if (kt + 1 < nk && ((kt & (MAX_NK - 1)) != 0 || kt == 0)) wait_vm<PER_STAGE>();
         else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         if (kt + 2 < nk) stage((kt + 2) % NSLOT, kt + 2);
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8_mx(GemmArgs g) {
             wf[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
         // this K-step's exponent byte of every tile (byte kt & 3 of dword kt >> 2, moved to byte 0: opsel 0)
-        const int sh = 8 * (kt & 3), qd = kt >> 2;
+        const int sh = 8 * (kt & 3), qd = (kt & (MAX_NK - 1)) >> 2;
         int sa[TM], sw[TN];
 #pragma unroll
         for (int i = 0; i < TM; i++) sa[i] = (int)((qd == 0 ? ea[i][0] : qd == 1 ? ea[i][1] : qd == 2 ? ea[i][2] : ea[i][3]) >> sh);
@@ -171,6 +179,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8_mx(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < TN; j++)   // D rows = n (first operand), cols = m
                 acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, sw[j], 0, sa[i]);
+        if ((kt & (MAX_NK - 1)) == MAX_NK - 1 && kt + 1 < nk) load_segment((kt + 1) / MAX_NK);   // next segment's exponents
     }
     __builtin_amdgcn_s_barrier();   // every wave is done with the ring: it becomes the output staging area
 
@@ -248,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8_mx(GemmArgs g) {
                     *reinterpret_cast<i32x4*>(C + (long)m * g.ldc + n) = pk;
                     if ((lane & 1) == 0) {
                         const int blk = n >> 5;
-                        g.c_sc[((long)m * 4 + (blk & 3)) * (g.N >> 7) + (blk >> 2)] = (unsigned char)eb;
+                        g.c_sc[((long)m * 4 + (blk & 3)) * wh_mx_nkp(g.N) + (blk >> 2)] = (unsigned char)eb;
                     }
                 }
             }
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8_mx(GemmArgs g) {
 template <int NV>
 __global__ __launch_bounds__(256) void k_layernorm_mx(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                       unsigned char* __restrict__ codes, unsigned char* __restrict__ exps, long rows) {
-    constexpr int d = 256 * NV, nk = d >> 7, NB = d >> 5;
+    constexpr int d = 256 * NV, nk = d >> 7, NB = d >> 5, nkp = nk < 4 ? nk : (nk + 3) / 4 * 4, NE = 4 * nkp;   // NE exponent bytes per row
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -327,16 +336,17 @@ __global__ __launch_bounds__(256) void k_layernorm_mx(const float* __restrict__ 
         *reinterpret_cast<int*>(codes + row * d + c) = pk;
         ebs[i] = eb;
     }
-    // exponent byte at layout position j = (blk & 3) * nk + (blk >> 2)  <=>  blk = (j / nk) + 4 * (j % nk); block blk was
-    // computed in sweep blk >> 3 by the lanes 8 * (blk & 7) .. + 7
-    const int j = lane < NB ? lane : 0, blk = (j / nk) + 4 * (j % nk), src = 8 * (blk & 7), sweep = blk >> 3;
-    int mine = 0;
+    // exponent byte at layout position j = (blk & 3) * nkp + (blk >> 2)  <=>  blk = (j / nkp) + 4 * (j % nkp), a padding byte
+    // where j % nkp >= nk (written as 2^0, never used); block blk was computed in sweep blk >> 3 by the lanes 8 * (blk & 7) .. + 7
+    static_assert(NE <= 64, "one lane per exponent byte");
+    const int j = lane < NE ? lane : 0, kt = j % nkp, blk = min((j / nkp) + 4 * kt, NB - 1), src = 8 * (blk & 7), sweep = blk >> 3;
+    int mine = 127;
 #pragma unroll
     for (int i = 0; i < NV; i++) {
         const int got = __shfl(ebs[i], src);
-        mine = (sweep == i) ? got : mine;
+        mine = (sweep == i && kt < nk) ? got : mine;
     }
-    if (lane < NB) exps[row * NB + lane] = (unsigned char)mine;
+    if (lane < NE) exps[row * NE + lane] = (unsigned char)mine;
 }
 
 template <typename TO>
@@ -352,7 +362,7 @@ void launch_mx(hipStream_t s, const GemmArgs& g) {
 
 bool wh_gemm8_mx_applicable(const GemmArgs& g) {
     const int nk = g.K / BKB;
-    return g.M >= BM && g.N >= BN && (g.K % BKB) == 0 && (nk == 2 || nk == 4 || nk == 8 || nk == 16) && (g.N % 4) == 0 &&
+    return g.M >= BM && g.N >= BN && (g.K % BKB) == 0 && nk >= 2 && (g.N % 4) == 0 &&
            (g.n_per >= g.N || (g.n_per % 64) == 0) && g.m_per >= 8 && (!g.c_sc || ((g.N % 128) == 0 && g.m_per >= g.M && g.n_per >= g.N));
 }
 
@@ -374,6 +384,8 @@ void wh_launch_layernorm_mx(hipStream_t s, const float* x, const float* w, const
         case 256: hipLaunchKernelGGL(k_layernorm_mx<1>, grid, dim3(256), 0, s, x, w, b, cp, ep, rows); break;
         case 512: hipLaunchKernelGGL(k_layernorm_mx<2>, grid, dim3(256), 0, s, x, w, b, cp, ep, rows); break;
         case 1024: hipLaunchKernelGGL(k_layernorm_mx<4>, grid, dim3(256), 0, s, x, w, b, cp, ep, rows); break;
+        case 1280: hipLaunchKernelGGL(k_layernorm_mx<5>, grid, dim3(256), 0, s, x, w, b, cp, ep, rows); break;
+        case 1536: hipLaunchKernelGGL(k_layernorm_mx<6>, grid, dim3(256), 0, s, x, w, b, cp, ep, rows); break;
         case 2048: hipLaunchKernelGGL(k_layernorm_mx<8>, grid, dim3(256), 0, s, x, w, b, cp, ep, rows); break;
         default: wh_set_error("k_layernorm_mx: unsupported width %d", d); break;
     }

@@ -29,11 +29,11 @@ struct GemmArgs {
     // Chosen from the context's capacity, never from the call's clip count: a clip decodes identically alone or in a batch.
     bool small_ctx = false;
     // wh_gemm8_mx.hip (WH_PREC_FP8): A and W hold e4m3 codes (one byte per element; lda, ldw, a_bs, *_zs in elements = bytes)
-    // with E8M0 block exponents per (row, 32 consecutive k), layout [row][4][K/128]; null = no block exponents (weights)
+    // with E8M0 block exponents per (row, 32 consecutive k), layout [row][4][wh_mx_nkp(K)]; null = no block exponents (weights)
     const unsigned char* a_sc = nullptr;
     const unsigned char* w_sc8 = nullptr;
     long a_sc_zs = 0, w_sc_zs = 0;
-    unsigned char* c_sc = nullptr;   // MX output: block exponents of C (C itself receives the codes), layout [row][4][N/128]
+    unsigned char* c_sc = nullptr;   // MX output: block exponents of C (C itself receives the codes), layout [row][4][wh_mx_nkp(N)]
 };
 
 struct SkinnyArgs {
@@ -118,6 +118,10 @@ void wh_launch_gemm(hipStream_t s, int prec, bool out_f32, const GemmArgs& g);
 // wh_gemm8.hip: the 8-wave LDS-DMA kernel (bf16 operands) for problems with at least one full 256 x 128 tile
 bool wh_gemm8_applicable(const GemmArgs& g);
 void wh_launch_gemm8(hipStream_t s, bool out_f32, const GemmArgs& g);
+// MX block exponents of a [rows][K] operand: [row][4][nkp] bytes, nkp = K-steps of 128 rounded up to a multiple of 4 (from 4 on)
+// so that the bytes of 16 consecutive K-steps are four aligned dwords
+__host__ __device__ inline int wh_mx_nkp(int K) { const int nk = K >> 7; return nk < 4 ? nk : (nk + 3) / 4 * 4; }
+inline bool wh_mx_ln_width(int d) { return d == 256 || d == 512 || d == 1024 || d == 1280 || d == 1536 || d == 2048; }   // k_layernorm_mx instantiations
 // wh_gemm8_mx.hip: e4m3 x e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4 (out: 0 bf16, 1 f32, 2 MX codes + exponents), and the
 // LayerNorm that produces MX activations
 bool wh_gemm8_mx_applicable(const GemmArgs& g);

@@ -29,8 +29,9 @@ constexpr int N_FFT = 400;
 constexpr int HOP = 160;
 constexpr int N_FREQ = 201;
 constexpr int NBIN_PAD = 208;  // 13 tiles of 16
-constexpr int FR_BLK = 16;     // frames per workgroup
-constexpr int SPAN = (FR_BLK - 1) * HOP + N_FFT;  // 2800 samples
+// frames per workgroup (FRB, template parameter): 16 = one full MFMA tile of the filterbank (2800 staged samples, 65 KB of
+// LDS, two workgroups per CU) or 8 (1520 samples, 34 KB, four workgroups per CU: the kernel is a chain of barrier-separated
+// latency phases, and four independent chains per CU overlap better than two — wh_launch_mel_stft picks, measured)
 
 // padded-signal sample i of a clip with n samples (src/main.rs:419-435)
 __device__ __forceinline__ float padded_sample(const float* __restrict__ pcm, long n, long i) {
@@ -84,13 +85,14 @@ __device__ __forceinline__ void dft8(const cplx (&a)[8], cplx (&y)[8]) {
     y[3] = c3 + w7; y[7] = c3 - w7;
 }
 
-constexpr int MEL_THREADS = 512;   // 16 frames x 32 threads: the FFT stages are latency chains, more lanes per frame shorten them
-
-__global__ __launch_bounds__(MEL_THREADS) void k_mel_stft(const float* __restrict__ pcm, long pcm_stride,
+// FRB frames x 32 threads: the FFT stages are latency chains, more lanes per frame shorten them
+template <int FRB>
+__global__ __launch_bounds__(FRB * 32) void k_mel_stft(const float* __restrict__ pcm, long pcm_stride,
                                                   const int* __restrict__ n_samples, const double* __restrict__ tw_g,
                                                   const float* __restrict__ win_g, const float* __restrict__ fbT,
                                                   int n_mels, float* __restrict__ raw, long raw_clip_stride,
                                                   long raw_row_stride, unsigned* __restrict__ gmax) {
+    constexpr int FR_BLK = FRB, MEL_THREADS = FRB * 32, SPAN = (FRB - 1) * HOP + N_FFT;
     __shared__ __attribute__((aligned(16))) real_t tw[N_FFT];
     __shared__ __attribute__((aligned(16))) float smp[SPAN];
     __shared__ __attribute__((aligned(16))) float win[N_FFT];
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(MEL_THREADS) void k_mel_stft(const float* __restric
 #pragma unroll 13
         for (int step = 0; step < NBIN_PAD / 4; step++) {
             const int k = 4 * step + g;
-            float a = pw[fl][k];
+            float a = pw[fl & (FR_BLK - 1)][k];   // (FRB = 8: rows 8..15 of the tile repeat rows 0..7 and are not stored)
             float b = fbT[(long)k * n_mels + mel];
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
         }
@@ -236,9 +238,11 @@ __global__ __launch_bounds__(MEL_THREADS) void k_mel_stft(const float* __restric
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             v[r] = log10f(fmaxf(acc[r], 1e-10f));  // src/main.rs:489,496
-            if (f0 + 4 * g + r < n_frames) lmax = fmaxf(lmax, v[r]);
+            if (4 * g < FR_BLK && f0 + 4 * g + r < n_frames) lmax = fmaxf(lmax, v[r]);
         }
-        if (f0 + 4 * g + 3 < n_frames) {
+        if (4 * g >= FR_BLK) {
+            // (FRB = 8: the upper half of the tile belongs to the next workgroup)
+        } else if (f0 + 4 * g + 3 < n_frames) {
             store4(out, v[0], v[1], v[2], v[3]);
         } else {
 #pragma unroll
@@ -347,10 +351,19 @@ void wh_build_mel_tables(int n_mels, std::vector<double>& tw, std::vector<float>
 void wh_launch_mel_stft(hipStream_t s, const float* pcm, long pcm_stride, const int* n_samples, int n_clips,
                         long max_frames, const double* tw, const float* win, const float* fbT, int n_mels, float* raw,
                         long raw_clip_stride, long raw_row_stride, unsigned* gmax) {
-    dim3 grid((unsigned)((max_frames + FR_BLK - 1) / FR_BLK), (unsigned)n_clips);
-    const size_t sm = (size_t)2 * FR_BLK * N_HALF * sizeof(cplx);   // the two FFT buffers: 100 KiB
-    wh_ensure_dyn_lds((const void*)k_mel_stft, sm);
-    hipLaunchKernelGGL(k_mel_stft, grid, dim3(MEL_THREADS), sm, s, pcm, pcm_stride, n_samples, tw, win, fbT, n_mels, raw,
+    static const int frb = [] { const char* e = getenv("WH_MEL_FRB"); return e ? atoi(e) : 16; }();
+    if (frb == 8) {
+        dim3 grid((unsigned)((max_frames + 7) / 8), (unsigned)n_clips);
+        const size_t sm = (size_t)2 * 8 * N_HALF * sizeof(cplx);    // the two FFT buffers
+        wh_ensure_dyn_lds((const void*)k_mel_stft<8>, sm);
+        hipLaunchKernelGGL(k_mel_stft<8>, grid, dim3(8 * 32), sm, s, pcm, pcm_stride, n_samples, tw, win, fbT, n_mels, raw,
+                           raw_clip_stride, raw_row_stride, gmax);
+        return;
+    }
+    dim3 grid((unsigned)((max_frames + 15) / 16), (unsigned)n_clips);
+    const size_t sm = (size_t)2 * 16 * N_HALF * sizeof(cplx);       // the two FFT buffers: 50 KiB
+    wh_ensure_dyn_lds((const void*)k_mel_stft<16>, sm);
+    hipLaunchKernelGGL(k_mel_stft<16>, grid, dim3(16 * 32), sm, s, pcm, pcm_stride, n_samples, tw, win, fbT, n_mels, raw,
                        raw_clip_stride, raw_row_stride, gmax);
 }
 
