@@ -15,3 +15,8 @@ for e in 32 48 64 80; do
   python3 -c "import json;j=json.load(open('$O/bench_pipe_e${e}_dall.json'));print(j['value'],j['ms_per_step'],j['stage_ms_per_step'],j['roofline']['frac'],j['kernel_group_ms_per_step'])"
 done
 timeout -k 10 100 ./tools/cu_mask_probe > $O/cu_mask_probe.txt 2>&1; echo "probe rc $?"; grep -v "^    xcc" $O/cu_mask_probe.txt | tail -25
+timeout -k 10 600 python -m pytest tests -m gpu -x -q -k "bit_identical or largest_batch_rows or teacher_forced_agreement or batched_contexts" > $O/pytest_tile.log 2>&1; echo "tile kernel tests rc $?"; tail -6 $O/pytest_tile.log
+for w in -3 -1; do
+  WH_DEC_WIDE=$w timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-batch1 --no-row-check > $O/bench_decwide$w.json 2> $O/bench_decwide$w.err; echo "bench WH_DEC_WIDE=$w rc $?"
+  python3 -c "import json;j=json.load(open('$O/bench_decwide$w.json'));print(j['value'],j['ms_per_step'],j['stage_ms_per_step'],j['kernel_group_ms_per_step'])"
+done
