@@ -488,16 +488,15 @@ def test_f32_base_batched_contexts_match_golden(gpu, golden_dir, nb):
 
 @pytest.mark.parametrize("prec_name", ["bf16", "fp8"])
 def test_wide_batch_decode_gemm_is_bit_identical(gpu, monkeypatch, prec_name):
-    """k_dec_gemm_wide (several 16-column tiles per workgroup) and k_dec_gemm_tile (64 x 64 / 64 x 128 LDS-shared tiles, bf16
-    weights; the kernel hundreds of rows get by default), both chosen from the batch size, against k_dec_gemm on the same
-    512-clip context: same K segments, same summation order — tokens and every logit bit-identical, whichever kernel runs."""
+    """k_dec_gemm_wide (several 16-column tiles per workgroup, chosen from the batch size) against k_dec_gemm on the same
+    512-clip context: same K split, same summation order — tokens and every logit bit-identical, whichever tile count runs."""
     prec = wb.PRECISIONS[prec_name]
     model = wb.Model("synthetic:base:1234", 0, prec)
     prompt, eot = [50258, 50259, 50359, 50363], 50257
     clips = [ms.synth_clip(700 + i) for i in range(8)]
     forced = np.random.Generator(np.random.PCG64(11)).integers(0, 50257, size=5).tolist()
     res = {}
-    modes = ("0", "-1", "2", "4", "64", "128")   # k_dec_gemm only | heuristic | wide NT = 2 / 4 | tile BN = 64 / 128 (bf16 weights only)
+    modes = ("0", "-1", "2", "4")   # k_dec_gemm only | heuristic | NT = 2 / 4 forced
     for wide in modes:
         monkeypatch.setenv("WH_DEC_WIDE", wide)
         ctx = wb.Context(model, 512)

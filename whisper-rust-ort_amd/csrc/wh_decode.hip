@@ -28,7 +28,6 @@
 
 #include <algorithm>
 #include <mutex>
-#include <type_traits>
 #include <unordered_map>
 
 // tuning knobs (tools/microbench.cpp flips them; product code leaves the defaults)
@@ -38,7 +37,6 @@ int wh_dbg_lm_mt = 4;
 int wh_dbg_mt = 0;
 int wh_dbg_nw = 0;   // 4 / 8: force the K split of the decode GEMM (0 = heuristic)
 int wh_dbg_wide = -1;  // column tiles per workgroup at > 256 rows: -1 heuristic, 0 off (k_dec_gemm only), 2 / 4 forced
-int wh_dbg_tile_min_rows = 256;   // rows from which the LDS tile kernel (k_dec_gemm_tile) takes the bf16 decode GEMMs
 
 namespace {
 
@@ -533,204 +531,6 @@ __global__ __launch_bounds__(NW * 64, 2) void k_dec_gemm_wide(SkinnyArgs a) {
                 const long tile = (long)blockIdx.x * NT + t / MT;
                 a.stats_out[(tile * a.x_mpad + em[j]) * 2] = s1;
                 a.stats_out[(tile * a.x_mpad + em[j]) * 2 + 1] = s2;
-            }
-        }
-    }
-    advance_if_last(a.ticket, a.pos_w, gridDim.x * gridDim.y);
-}
-
-// ---- decode GEMM for batches of hundreds of rows: LDS-shared tiles -------------------------------------------------------
-// At 256+ rows the decode GEMMs are real GEMMs (M = 1024, N, K in 512 .. 2048 at whisper-base); k_dec_gemm(_wide) pulls every
-// weight and activation fragment through each wave's own registers, i.e. a workgroup's operand bytes once per wave that
-// needs them.  Here a workgroup owns a 64 x BN output tile and streams its operands ONCE through LDS with the LDS-DMA path
-// (global_load_lds_dwordx4, a ring of k-steps with counted vmcnt waits and one barrier per k-step, source-side bank swizzle:
-// the structure of k_gemm8) — the slab layout [K/32][mpad][32] of the decode activations is exactly an LDS tile per k-step.
-// Each of the four waves owns a sub-tile over the whole K.
-//
-// Bit-identical to k_dec_gemm: that kernel splits K NSPLIT ways over its waves and adds the partial sums in wave order,
-// ((p0 + p1) + p2) + ...; here a wave accumulates one K segment at a time into a second register set with the same MFMA
-// sequence (same operands per instruction) and folds it into the running sum in the same order.  LayerNorm partial sums are
-// reduced in the same order, the epilogue expressions are the same.  So the choice of kernel may follow the call's batch
-// size: a clip's arithmetic does not change (tests/test_hip_parity.py::test_wide_batch_decode_gemm_is_bit_identical).
-// bf16 operands only; no merged-X (attention partials) variant: large batches run one key range per clip.
-typedef const __attribute__((address_space(1))) void* dg_gptr_t;
-typedef __attribute__((address_space(3))) void* dg_lptr_t;
-template <int N> __device__ __forceinline__ void dg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <typename TO, int BN, int NSPLIT>
-__global__ __launch_bounds__(256) void k_dec_gemm_tile(SkinnyArgs a) {
-    typedef bf16 T;
-    constexpr int BM = 64, ROWB = 64;                       // 64-byte LDS rows: 32 k of bf16
-    constexpr int WN = 2, WM = 2;                            // waves along n / m
-    constexpr int TMW = BM / WM / 16, TNW = BN / WN / 16;    // 16 x 16 MFMA tiles per wave: 2 x {2, 4}
-    constexpr int NI = (BM + BN) / 16, PS = NI / 4;          // LDS-DMA instructions (1 KiB = 16 rows) per stage / per wave
-    static_assert(NI % 4 == 0, "every wave issues the same number of LDS-DMA instructions per stage");
-    constexpr int SLOT = (BM + BN) * ROWB;
-    constexpr int NSLOT = BN == 128 ? 6 : 8;                 // 72 / 64 KiB: two workgroups per CU at BN = 64
-    extern __shared__ __attribute__((aligned(16))) char tsm[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int fl = lane & 15, fg = lane >> 4;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
-    const int nk = a.K >> 5, seg = nk / NSPLIT;              // k-steps in all / per K segment (launcher: K % (32 * NSPLIT) == 0)
-
-    // LayerNorm partial sums of this row group (consumers), the per-column operands and the residual rows: requested first,
-    // so that they are older than every LDS-DMA request (vmcnt retires in order: the counted waits below stay exact)
-    float* lnred = reinterpret_cast<float*>(tsm + (size_t)NSLOT * SLOT);   // [4][64][2]
-    float ps1 = 0.0f, ps2 = 0.0f;
-    if (a.ln_part) ln_partial_sum(a.ln_part, a.ln_tiles, a.x_mpad, m0 + (tid & 63), tid >> 6, 4, ps1, ps2);
-    f32x4 pre_bias[TNW], pre_sv[TNW], pre_r[TMW][TNW];
-    const int en0 = n0 + wn * (TNW * 16) + 4 * fg, em0 = m0 + wm * (TMW * 16) + fl;
-#pragma unroll
-    for (int j = 0; j < TNW; j++) {
-        const int en = en0 + j * 16;
-        pre_bias[j] = f32x4{0, 0, 0, 0};
-        pre_sv[j] = f32x4{0, 0, 0, 0};
-        if (en < a.N) {
-            if (a.bias) pre_bias[j] = *reinterpret_cast<const f32x4*>(a.bias + en);
-            if (a.ln_part) pre_sv[j] = *reinterpret_cast<const f32x4*>(a.ln_s + en);
-        }
-#pragma unroll
-        for (int i = 0; i < TMW; i++) {
-            pre_r[i][j] = f32x4{0, 0, 0, 0};
-            if (a.R && en < a.N && em0 + i * 16 < a.M) pre_r[i][j] = *reinterpret_cast<const f32x4*>(a.R + (long)(em0 + i * 16) * a.ldr + en);
-        }
-    }
-
-    // this wave's share of a stage: instruction q = wave + 4 u covers 16 rows — rows 16 q .. of the activation tile (q < 4) or
-    // rows 16 (q - 4) .. of the weight tile; lane i -> row i / 4, 16-byte chunk i % 4, bank swizzle on the source side
-    const int rl = lane >> 2, pc = lane & 3;
-    const T* src[PS];
-    long kstride[PS];
-    int dst[PS];
-#pragma unroll
-    for (int u = 0; u < PS; u++) {
-        const int q = wave + 4 * u;
-        if (q < BM / 16) {
-            const int r = 16 * q + rl;
-            src[u] = (const T*)a.X + ((long)(m0 + r)) * 32 + ((pc ^ ((r >> 2) & 2)) << 3);
-            kstride[u] = (long)a.x_mpad * 32;               // next k-slab
-            dst[u] = 16 * q * ROWB;
-        } else {
-            const int r = 16 * (q - BM / 16) + rl;
-            src[u] = (const T*)a.W + (long)min(n0 + r, a.N - 1) * a.K + ((pc ^ ((r >> 2) & 2)) << 3);
-            kstride[u] = 32;
-            dst[u] = BM * ROWB + 16 * (q - BM / 16) * ROWB;
-        }
-    }
-    auto stage = [&](int slot, int kt) {
-#pragma unroll
-        for (int u = 0; u < PS; u++)
-            __builtin_amdgcn_global_load_lds((dg_gptr_t)(src[u] + kt * kstride[u]), (dg_lptr_t)(tsm + slot * SLOT + dst[u]), 16, 0, 0);
-    };
-    auto wait_stage = [&](int kt) {   // stage kt has landed; the younger stages issued so far stay in flight
-        const int newer = min(NSLOT - 2, nk - 1 - kt);
-        switch (newer) {
-            case 0: dg_wait_vm<0>(); break;
-            case 1: dg_wait_vm<PS>(); break;
-            case 2: dg_wait_vm<2 * PS>(); break;
-            case 3: dg_wait_vm<3 * PS>(); break;
-            case 4: dg_wait_vm<4 * PS>(); break;
-            case 5: dg_wait_vm<5 * PS>(); break;
-            default: dg_wait_vm<6 * PS>(); break;
-        }
-    };
-    static_assert(NSLOT - 2 <= 6, "wait_stage covers up to six younger stages");
-#pragma unroll
-    for (int t = 0; t < NSLOT - 1; t++)
-        if (t < nk) stage(t, t);
-
-    float ln_mean[TMW], ln_rstd[TMW];
-#pragma unroll
-    for (int i = 0; i < TMW; i++) { ln_mean[i] = 0.0f; ln_rstd[i] = 1.0f; }
-    if (a.ln_part) {   // (quarter q = tid >> 6, row r = tid & 63) partial sums -> mean / rstd, in k_dec_gemm's order
-        lnred[((tid >> 6) * 64 + (tid & 63)) * 2] = ps1;
-        lnred[((tid >> 6) * 64 + (tid & 63)) * 2 + 1] = ps2;
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < TMW; i++) {
-            constexpr int ROWS = 64;
-            const int r = wm * (TMW * 16) + i * 16 + fl;
-            const float s1 = (lnred[r * 2] + lnred[(ROWS + r) * 2]) + (lnred[(2 * ROWS + r) * 2] + lnred[(3 * ROWS + r) * 2]);
-            const float s2 = (lnred[r * 2 + 1] + lnred[(ROWS + r) * 2 + 1]) + (lnred[(2 * ROWS + r) * 2 + 1] + lnred[(3 * ROWS + r) * 2 + 1]);
-            ln_mean[i] = s1 / (float)a.K;
-            ln_rstd[i] = rsqrtf(fmaxf(s2 / (float)a.K - ln_mean[i] * ln_mean[i], 0.0f) + 1e-5f);
-        }
-    }
-
-    f32x4 acc[TMW][TNW], part[TMW][TNW];
-    const int ch = (fg ^ ((fl >> 2) & 2)) << 4;
-    const int a_off = (wm * (TMW * 16) + fl) * ROWB + ch, w_off = BM * ROWB + (wn * (TNW * 16) + fl) * ROWB + ch;
-    int kt = 0;
-#pragma unroll
-    for (int sg = 0; sg < NSPLIT; sg++) {
-#pragma unroll
-        for (int i = 0; i < TMW; i++)
-#pragma unroll
-            for (int j = 0; j < TNW; j++) part[i][j] = f32x4{0, 0, 0, 0};
-        for (int it = 0; it < seg; it++, kt++) {
-            wait_stage(kt);
-            __builtin_amdgcn_s_barrier();   // stage kt visible to all; every wave has consumed the fragments of kt - 1
-            if (kt + NSLOT - 1 < nk) stage((kt + NSLOT - 1) % NSLOT, kt + NSLOT - 1);
-            const char* sb = tsm + (kt % NSLOT) * SLOT;
-            bf16x8 xf[TMW], wf[TNW];
-#pragma unroll
-            for (int i = 0; i < TMW; i++) xf[i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 16 * ROWB);
-#pragma unroll
-            for (int j = 0; j < TNW; j++) wf[j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 16 * ROWB);
-#pragma unroll
-            for (int i = 0; i < TMW; i++)
-#pragma unroll
-                for (int j = 0; j < TNW; j++) mma16(part[i][j], wf[j], xf[i]);   // D rows = n (4*fg + r), col = m (fl)
-        }
-#pragma unroll
-        for (int i = 0; i < TMW; i++)
-#pragma unroll
-            for (int j = 0; j < TNW; j++) {
-                if (sg == 0) acc[i][j] = part[i][j];
-                else { acc[i][j][0] += part[i][j][0]; acc[i][j][1] += part[i][j][1]; acc[i][j][2] += part[i][j][2]; acc[i][j][3] += part[i][j][3]; }
-            }
-    }
-
-    // ---- epilogue: k_dec_gemm's, per 16 x 16 tile ---------------------------------------------------------------------
-#pragma unroll
-    for (int i = 0; i < TMW; i++) {
-        const int em = em0 + i * 16;
-#pragma unroll
-        for (int j = 0; j < TNW; j++) {
-            const int en = en0 + j * 16;
-            const bool ok = en < a.N && em < a.M;
-            const f32x4 s = acc[i][j];
-            if (ok) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    v[e] = a.ln_part ? ln_rstd[i] * (s[e] - ln_mean[i] * pre_sv[j][e]) + pre_bias[j][e] : s[e] + pre_bias[j][e];
-                    if (a.act == 1) v[e] = gelu_erf(v[e]);
-                    v[e] += pre_r[i][j][e];
-                }
-                TO* dstp = a.c_mpad ? (TO*)a.C + slab_idx(em, en, a.c_mpad) : (TO*)a.C + (long)em * a.ldc + en;
-                store4(dstp, v[0], v[1], v[2], v[3]);
-                if (a.xslab_out) store4((T*)a.xslab_out + slab_idx(em, en, a.x_mpad), v[0], v[1], v[2], v[3]);
-            }
-            if (a.stats_out) {   // this 16-column tile's {sum x, sum x^2} per row (producers have no activation)
-                float s1 = 0.0f, s2 = 0.0f;
-                if (ok) {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const float u = s[e] + pre_bias[j][e] + pre_r[i][j][e];
-                        s1 += u;
-                        s2 += u * u;
-                    }
-                }
-                s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-                if (fg == 0 && em < a.M) {
-                    const long tile = (en - 4 * fg) >> 4;
-                    a.stats_out[(tile * a.x_mpad + em) * 2] = s1;
-                    a.stats_out[(tile * a.x_mpad + em) * 2 + 1] = s2;
-                }
             }
         }
     }
@@ -1437,32 +1237,7 @@ void launch_dec_gemm_mt(hipStream_t s, const SkinnyArgs& a) {
     if (a.M > 64 && !a.xpart && wh_dbg_mt <= 0 && a.K % (NW * 4 * WTraits<T, TW>::KW) == 0) {
         constexpr int WMT = 4;
         int wide = wh_dbg_wide;
-        if (const char* e = getenv("WH_DEC_WIDE")) wide = atoi(e);   // A/B switch for the parity test (0: k_dec_gemm only, -2 / 64 / 128: the LDS tile kernel)
-        // hundreds of rows, bf16 weights: the LDS-shared tile kernel (bit-identical too).  64 x 128 tiles while they still give
-        // >= 128 workgroups, else 64 x 64 (measured: tools/dec_gemm_sweep.cpp, profiles/r03_dec_gemm_tile.txt)
-        if constexpr (std::is_same<TW, bf16>::value) {
-            const int rgt = (a.M + 63) / 64;
-            int bn = 0;
-            if (a.M >= wh_dbg_tile_min_rows && a.wscale == nullptr && a.xgamma == nullptr) {
-                if (a.N % 128 == 0 && (a.N / 128) * rgt >= 128) bn = 128;
-                else if (a.N % 64 == 0) bn = 64;
-            }
-            if (wide == 64 || wide == 128) bn = (a.N % wide == 0) ? wide : 0;
-            else if (wide != -1 && wide != -2) bn = 0;
-            if (bn) {
-                dim3 gt(a.N / bn, rgt);
-                if (bn == 128) {
-                    const size_t sm = (size_t)6 * (64 + 128) * 64 + 4 * 64 * 2 * 4;
-                    set_max_smem(k_dec_gemm_tile<TO, 128, NW>, sm);
-                    hipLaunchKernelGGL((k_dec_gemm_tile<TO, 128, NW>), gt, dim3(256), sm, s, a);
-                } else {
-                    const size_t sm = (size_t)8 * (64 + 64) * 64 + 4 * 64 * 2 * 4;
-                    set_max_smem(k_dec_gemm_tile<TO, 64, NW>, sm);
-                    hipLaunchKernelGGL((k_dec_gemm_tile<TO, 64, NW>), gt, dim3(256), sm, s, a);
-                }
-                return;
-            }
-        }
+        if (const char* e = getenv("WH_DEC_WIDE")) wide = atoi(e);   // A/B switch for the parity test (0: k_dec_gemm only)
         const int rg = (a.M + 16 * WMT - 1) / (16 * WMT);
         // measured (tools/dec_gemm_sweep.cpp, profiles/r02_dec_gemm_sweep.txt): four column tiles while >= 512 workgroups
         // remain (fc1 at 1024 rows: 11.7 vs 13.2 us), else two while >= 128 remain (1280 x 1280 at 256 rows: 8.5 vs 11.3 us;

@@ -158,5 +158,4 @@ extern int wh_dbg_lm_blocks_per_cu;
 extern int wh_dbg_mt;
 extern int wh_dbg_nw;
 extern int wh_dbg_wide;
-extern int wh_dbg_tile_min_rows;
 extern int wh_dbg_lm_mt;

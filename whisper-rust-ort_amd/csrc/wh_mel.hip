@@ -30,8 +30,9 @@ constexpr int HOP = 160;
 constexpr int N_FREQ = 201;
 constexpr int NBIN_PAD = 208;  // 13 tiles of 16
 // frames per workgroup (FRB, template parameter): 16 = one full MFMA tile of the filterbank (2800 staged samples, 65 KB of
-// LDS, two workgroups per CU) or 8 (1520 samples, 34 KB, four workgroups per CU: the kernel is a chain of barrier-separated
-// latency phases, and four independent chains per CU overlap better than two — wh_launch_mel_stft picks, measured)
+// LDS, two workgroups per CU).  8 frames (1520 samples, 34 KB, four workgroups per CU: four independent barrier-separated
+// latency chains per CU instead of two) was measured in round 3 and is slower — 7.28 against 5.21 ms per 1024 clips: the same
+// waves per CU, but half of every filterbank MFMA tile idle and twice the per-workgroup fixed cost (tables, barriers).
 
 // padded-signal sample i of a clip with n samples (src/main.rs:419-435)
 __device__ __forceinline__ float padded_sample(const float* __restrict__ pcm, long n, long i) {
@@ -351,15 +352,6 @@ void wh_build_mel_tables(int n_mels, std::vector<double>& tw, std::vector<float>
 void wh_launch_mel_stft(hipStream_t s, const float* pcm, long pcm_stride, const int* n_samples, int n_clips,
                         long max_frames, const double* tw, const float* win, const float* fbT, int n_mels, float* raw,
                         long raw_clip_stride, long raw_row_stride, unsigned* gmax) {
-    static const int frb = [] { const char* e = getenv("WH_MEL_FRB"); return e ? atoi(e) : 16; }();
-    if (frb == 8) {
-        dim3 grid((unsigned)((max_frames + 7) / 8), (unsigned)n_clips);
-        const size_t sm = (size_t)2 * 8 * N_HALF * sizeof(cplx);    // the two FFT buffers
-        wh_ensure_dyn_lds((const void*)k_mel_stft<8>, sm);
-        hipLaunchKernelGGL(k_mel_stft<8>, grid, dim3(8 * 32), sm, s, pcm, pcm_stride, n_samples, tw, win, fbT, n_mels, raw,
-                           raw_clip_stride, raw_row_stride, gmax);
-        return;
-    }
     dim3 grid((unsigned)((max_frames + 15) / 16), (unsigned)n_clips);
     const size_t sm = (size_t)2 * 16 * N_HALF * sizeof(cplx);       // the two FFT buffers: 50 KiB
     wh_ensure_dyn_lds((const void*)k_mel_stft<16>, sm);
