@@ -488,17 +488,19 @@ def test_f32_base_batched_contexts_match_golden(gpu, golden_dir, nb):
 
 @pytest.mark.parametrize("prec_name", ["bf16", "fp8"])
 def test_wide_batch_decode_gemm_is_bit_identical(gpu, monkeypatch, prec_name):
-    """k_dec_gemm_wide (several 16-column tiles per workgroup, chosen from the batch size) against k_dec_gemm on the same
-    512-clip context: same K split, same summation order — tokens and every logit bit-identical, whichever tile count runs."""
+    """k_dec_gemm_wide (several 16-column tiles per workgroup) and k_lm_head_tile (the LM head on 256 x 256 LDS-DMA tiles), both
+    chosen from the batch size, against k_dec_gemm / k_lm_head on the same 512-clip context: same K split, same summation
+    order, same epilogue arithmetic — tokens and every logit bit-identical, whichever kernels run."""
     prec = wb.PRECISIONS[prec_name]
     model = wb.Model("synthetic:base:1234", 0, prec)
     prompt, eot = [50258, 50259, 50359, 50363], 50257
     clips = [ms.synth_clip(700 + i) for i in range(8)]
     forced = np.random.Generator(np.random.PCG64(11)).integers(0, 50257, size=5).tolist()
     res = {}
-    modes = ("0", "-1", "2", "4")   # k_dec_gemm only | heuristic | NT = 2 / 4 forced
+    modes = ("0", "-1", "2", "4", "lm")   # k_dec_gemm + k_lm_head only | heuristics (wide GEMM, tile LM head) | NT = 2 / 4 forced | only the LM head switched
     for wide in modes:
-        monkeypatch.setenv("WH_DEC_WIDE", wide)
+        monkeypatch.setenv("WH_DEC_WIDE", "0" if wide == "lm" else wide)
+        monkeypatch.setenv("WH_LM_TILE_MIN_ROWS", "0" if wide == "0" else "256")
         ctx = wb.Context(model, 512)
         toks = [t.tolist() for t in ctx.transcribe_batch([clips[i % 8] for i in range(512)], wb.DecodeParams(prompt, 24, eot, [eot]))]
         _, lg = ctx.greedy_decode_resident_batch(wb.DecodeParams(prompt, len(forced) + 1, eot, forced=forced), want_logits=True)

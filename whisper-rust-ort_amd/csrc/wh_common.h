@@ -174,6 +174,30 @@ __device__ __host__ __forceinline__ float ord2f(unsigned u) {
 #endif
 }
 
+// Sum of the LayerNorm partials {sum x, sum x^2} of row `row` over tiles q, q + step, q + 2 step, ... < n_tiles,
+// eight 8-byte loads in flight at a time (clamped re-reads are masked): a run-time loop with one load per
+// iteration costs one memory round trip per tile.
+__device__ __forceinline__ void ln_partial_sum(const float* __restrict__ part, int n_tiles, int x_mpad, int row, int q, int step,
+                                               float& s1, float& s2) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    s1 = 0.0f;
+    s2 = 0.0f;
+    for (int t0 = q; t0 < n_tiles; t0 += 8 * step) {
+        f32x2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int tl = min(t0 + u * step, n_tiles - 1);
+            v[u] = *reinterpret_cast<const f32x2*>(part + ((long)tl * x_mpad + row) * 2);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const bool ok = t0 + u * step < n_tiles;
+            s1 += ok ? v[u].x : 0.0f;
+            s2 += ok ? v[u].y : 0.0f;
+        }
+    }
+}
+
 #define WH_HIP_CHECK(expr)                                                                      \
     do {                                                                                        \
         hipError_t _e = (expr);                                                                 \

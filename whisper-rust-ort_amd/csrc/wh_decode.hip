@@ -143,30 +143,6 @@ __device__ __forceinline__ f32x4 partials_merge(const SkinnyArgs& a, PartRaw<SP>
     return acc;
 }
 
-// Sum of the LayerNorm partials {sum x, sum x^2} of row `row` over tiles q, q + step, q + 2 step, ... < n_tiles,
-// eight 8-byte loads in flight at a time (clamped re-reads are masked): a run-time loop with one load per
-// iteration costs one memory round trip per tile.
-__device__ __forceinline__ void ln_partial_sum(const float* __restrict__ part, int n_tiles, int x_mpad, int row, int q, int step,
-                                               float& s1, float& s2) {
-    typedef __attribute__((ext_vector_type(2))) float f32x2;
-    s1 = 0.0f;
-    s2 = 0.0f;
-    for (int t0 = q; t0 < n_tiles; t0 += 8 * step) {
-        f32x2 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int tl = min(t0 + u * step, n_tiles - 1);
-            v[u] = *reinterpret_cast<const f32x2*>(part + ((long)tl * x_mpad + row) * 2);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const bool ok = t0 + u * step < n_tiles;
-            s1 += ok ? v[u].x : 0.0f;
-            s2 += ok ? v[u].y : 0.0f;
-        }
-    }
-}
-
 // Weight operand of one k-step.  Native dtype: 8 consecutive k per lane (one MFMA per load).  e4m3 codes: 8 per lane
 // (fp8x8_t, one MFMA) or 16 per lane (fp8x16_t: one 16-byte load feeds two MFMAs — half the load instructions for
 // the same bytes); codes are dequantised in registers with v_cvt_scalef32_pk_bf16_fp8 (byte j of the dword is
@@ -1349,6 +1325,7 @@ void launch_lm_head_t(hipStream_t s, const SkinnyArgs& a, int* n_parts_out = nul
 // a.X = final-LayerNorm'ed rows [M][K] in the compute dtype
 void wh_launch_lm_head(hipStream_t s, int prec, const SkinnyArgs& a) {
     if (prec == WH_PREC_F32) launch_lm_head_t<float>(s, a);
+    else if (wh_lm_head_tile_applicable(a)) wh_launch_lm_head_tile(s, a);   // hundreds of rows: 256 x 256 tiles (wh_gemm8.hip), same logits
     else launch_lm_head_t<bf16>(s, a);
 }
 
@@ -1356,6 +1333,7 @@ void wh_launch_lm_head(hipStream_t s, int prec, const SkinnyArgs& a) {
 int wh_lm_head_parts(int prec, const SkinnyArgs& a) {
     int n = 0;
     if (prec == WH_PREC_F32) launch_lm_head_t<float>(nullptr, a, &n);
+    else if (wh_lm_head_tile_applicable(a)) n = wh_lm_head_tile_parts(a);
     else launch_lm_head_t<bf16>(nullptr, a, &n);
     return n;
 }

@@ -33,6 +33,8 @@
 //     16-byte ones at 5 TB/s); the f32 residual is read the same way.  No workgroup barrier in the epilogue.
 //   * XCD-aware tile order as in k_gemm: one XCD walks a contiguous run of tiles, n fastest, so the column tiles that share
 //     an activation row panel reuse it from that XCD's L2.
+#include <stdlib.h>
+
 #include "wh_common.h"
 #include "wh_kernels.h"
 
@@ -293,6 +295,192 @@ __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs
     }
 }
 
+
+// ---- the LM head at hundreds of rows on the same tile structure ------------------------------------------------------------
+// logits = LN(x) · E^T over the whole vocabulary + masked argmax partials (k_lm_head's contract, wh_decode.hip; reference
+// argmax_last_dim_raw, src/main.rs:709-735).  k_lm_head stages a 64-row activation tile per workgroup and streams the 53 MB
+// tied embedding once per 64 rows: 850 MB through L2 per launch at 1024 rows.  Here a workgroup owns a 256 x 256 logit tile
+// (k_gemm8's BN = 256 geometry and LDS-DMA ring; the activation rows come from the decode slab layout [K/32][mpad][32], which
+// is an LDS tile per k-step as it stands), so the embedding passes L2 once per 256 rows; the epilogue never stores the tile —
+// it folds the final LayerNorm (rstd (acc - mean s[n]) + c[n]), applies the suppress mask and keeps one (max, index) per row and
+// wave: one partial per (column tile, wave column) and row.
+// Bit-identical logits: the same MFMA chain over k as k_lm_head (weights as the row operand, k ascending, one accumulator),
+// LayerNorm partial sums reduced in the same order, the same epilogue expression — so the launcher may pick by the call's
+// row count (tests/test_hip_parity.py::test_wide_batch_decode_gemm_is_bit_identical runs both).
+__global__ __launch_bounds__(512, 2) void k_lm_head_tile(SkinnyArgs a) {
+    typedef Geo<256> G;
+    constexpr int BN = 256, TM = G::TM, TN = G::TN, NSLOT = G::NSLOT, SLOT = G::SLOT, SLOT_A = G::SLOT_A;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / G::WN, wn = wave % G::WN;
+    const int fl = lane & 15, fg = lane >> 4;
+    const int nk = a.K / BK;
+    const int nbn = (a.N + BN - 1) / BN;
+    const int total = nbn * ((a.M + BM - 1) / BM);
+    int tile = blockIdx.x;
+    {
+        const int q = total >> 3, r = total & 7, xcd = tile & 7, idx = tile >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int ct = tile % nbn, m0 = (tile / nbn) * BM, n0 = ct * BN;
+
+    // final LayerNorm: quarter sums of the producer's per-tile partials, two quarters per thread (row tid & 255) — requested
+    // before the ring, so they are the oldest vector-memory requests
+    float* lnstat = reinterpret_cast<float*>(smem + (size_t)NSLOT * SLOT);   // [256][2] mean, rstd
+    float* lnq = lnstat + 2 * BM;                                            // [4][256][2]
+    if (a.ln_part) {
+        const int r = tid & (BM - 1), h = tid >> 8, row = min(m0 + r, a.x_mpad - 1);
+        float s1a, s2a, s1b, s2b;
+        ln_partial_sum(a.ln_part, a.ln_tiles, a.x_mpad, row, h, 4, s1a, s2a);
+        ln_partial_sum(a.ln_part, a.ln_tiles, a.x_mpad, row, h + 2, 4, s1b, s2b);
+        lnq[(h * BM + r) * 2] = s1a;
+        lnq[(h * BM + r) * 2 + 1] = s2a;
+        lnq[((h + 2) * BM + r) * 2] = s1b;
+        lnq[((h + 2) * BM + r) * 2 + 1] = s2b;
+    }
+
+    const int rl = lane >> 2, ps = lane & 3;
+    const bf16* a_src[2];
+    const bf16* w_src[2];
+    const long a_kstep = (long)a.x_mpad * 32;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int row = wave * 32 + j * 16 + rl;
+        a_src[j] = (const bf16*)a.X + (long)min(m0 + row, a.x_mpad - 1) * 32 + ((ps ^ swz(row)) << 3);
+        w_src[j] = (const bf16*)a.W + (long)min(n0 + row, a.N - 1) * a.K + ((ps ^ swz(row)) << 3);
+    }
+    auto stage = [&](int slot, int kt) {
+        char* base = smem + slot * SLOT;
+#pragma unroll
+        for (int j = 0; j < 2; j++) glds16(a_src[j] + kt * a_kstep, base + (wave * 32 + j * 16) * ROWB);
+#pragma unroll
+        for (int j = 0; j < 2; j++) glds16(w_src[j] + (long)kt * BK, base + SLOT_A + (wave * 32 + j * 16) * ROWB);
+    };
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0, 0, 0, 0};
+    const int ch = (fg ^ swz(fl)) << 4;
+    const int a_off = (wm * (TM * 16) + fl) * ROWB + ch;
+    const int w_off = SLOT_A + (wn * 64 + fl) * ROWB + ch;
+    bf16x8 af[2][TM], wf[2][TN];
+    auto read_frags = [&](int set, int kt) {
+        const char* sb = smem + (kt % NSLOT) * SLOT;
+#pragma unroll
+        for (int i = 0; i < TM; i++) af[set][i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 16 * ROWB);
+#pragma unroll
+        for (int j = 0; j < TN; j++) wf[set][j] = *reinterpret_cast<const bf16x8*>(sb + w_off + j * 16 * ROWB);
+    };
+    auto mfmas = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) mma16(acc[i][j], wf[set][j], af[set][i]);   // D rows = n, cols = m
+    };
+    auto wait_stage = [&](int kt, int cap) {
+        const int newer = min(cap, nk - 1 - kt);
+        constexpr int PS = G::PER_STAGE;
+        if (newer >= 3) wait_vm<3 * PS>();
+        else if (newer == 2) wait_vm<2 * PS>();
+        else if (newer == 1) wait_vm<PS>();
+        else wait_vm<0>();
+    };
+#pragma unroll
+    for (int t = 0; t < NSLOT; t++)
+        if (t < nk) stage(t, t);
+    wait_stage(0, NSLOT - 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's quarter sums have left for LDS
+    __builtin_amdgcn_s_barrier();          // stage 0 visible; the LayerNorm quarter sums are in LDS
+    if (a.ln_part && tid < BM) {
+        const float s1 = (lnq[tid * 2] + lnq[(BM + tid) * 2]) + (lnq[(2 * BM + tid) * 2] + lnq[(3 * BM + tid) * 2]);
+        const float s2 = (lnq[tid * 2 + 1] + lnq[(BM + tid) * 2 + 1]) + (lnq[(2 * BM + tid) * 2 + 1] + lnq[(3 * BM + tid) * 2 + 1]);
+        const float mean = s1 / (float)a.K;
+        lnstat[2 * tid] = mean;
+        lnstat[2 * tid + 1] = rsqrtf(fmaxf(s2 / (float)a.K - mean * mean, 0.0f) + 1e-5f);
+    }
+    read_frags(0, 0);
+    for (int kt = 0; kt < nk; kt += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int t = kt + h;
+            if (t >= nk) break;
+            if (t + 1 < nk) {
+                wait_stage(t + 1, NSLOT - 2);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (t + NSLOT < nk) stage(t % NSLOT, t + NSLOT);
+                read_frags(h ^ 1, t + 1);
+            }
+            mfmas(h);
+        }
+    }
+    __syncthreads();   // lnstat written by the first 256 threads is visible to everyone (and every MFMA has its operands)
+
+    // ---- epilogue: final LayerNorm fold + masked argmax, one partial per (wave, row) ------------------------------------
+    const int pos = *a.pos_p;
+    const int gen = pos - (a.n_prompt - 1);  // index of the token this row generates
+    const unsigned* mask = (gen == 0) ? a.mask_first : a.mask_base;
+    const int nw0 = n0 + wn * 64;
+    float sv[TN][4], cv[TN][4];
+    unsigned mbits[TN];
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = nw0 + j * 16 + 4 * fg;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { sv[j][e] = 0.0f; cv[j][e] = 0.0f; }
+        if (a.ln_part) {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (n + e < a.N) { sv[j][e] = a.ln_s[n + e]; cv[j][e] = a.bias[n + e]; }
+        }
+        mbits[j] = 0;
+        if (n < a.N) mbits[j] = mask[n >> 5] >> (n & 31);   // suppress bits of this lane's 4 columns
+    }
+    const int part = ct * G::WN + wn;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int rloc = wm * (TM * 16) + i * 16 + fl, m = m0 + rloc;
+        const float mean = a.ln_part ? lnstat[2 * rloc] : 0.0f, rstd = a.ln_part ? lnstat[2 * rloc + 1] : 1.0f;
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = nw0 + j * 16 + 4 * fg;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int nn = n + e;
+                const float v = a.ln_part ? rstd * (acc[i][j][e] - mean * sv[j][e]) + cv[j][e] : acc[i][j][e];
+                if (nn < a.N && m < a.M) {
+                    if (a.logits && gen >= 0 && gen < a.logits_rows) a.logits[((long)m * a.logits_rows + gen) * a.N + nn] = v;
+                    const bool sup = (mbits[j] >> e) & 1u;
+                    if (!sup && v > bv) { bv = v; bi = nn; }  // strict >, columns ascending: lowest index on ties, NaN never wins
+                }
+            }
+        }
+        // argmax over the four lane groups of the row (k_lm_head's reduction)
+        wh_u32x2 tv = __builtin_amdgcn_permlane16_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+        wh_u32x2 ti = __builtin_amdgcn_permlane16_swap((unsigned)bi, (unsigned)bi, false, false);
+        float v0 = __uint_as_float(tv.x), v1 = __uint_as_float(tv.y);
+        int i0 = (int)ti.x, i1 = (int)ti.y;
+        bool take1 = v1 > v0 || (v1 == v0 && i1 < i0);
+        bv = take1 ? v1 : v0;
+        bi = take1 ? i1 : i0;
+        tv = __builtin_amdgcn_permlane32_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+        ti = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
+        v0 = __uint_as_float(tv.x); v1 = __uint_as_float(tv.y);
+        i0 = (int)ti.x; i1 = (int)ti.y;
+        take1 = v1 > v0 || (v1 == v0 && i1 < i0);
+        bv = take1 ? v1 : v0;
+        bi = take1 ? i1 : i0;
+        if (fg == 0 && m < a.M) {
+            a.part_val[(long)part * a.x_mpad + m] = bv;
+            a.part_idx[(long)part * a.x_mpad + m] = bi;
+        }
+    }
+}
+
 template <typename TO, int BN>
 void launch8(hipStream_t s, const GemmArgs& g) {
     typedef Geo<BN> G;
@@ -309,6 +497,21 @@ bool wh_gemm8_applicable(const GemmArgs& g) {
     // N tails are handled by clamping + masking in 8-column groups (a last group of 4); the column-plane mapping needs 64-column granularity;
     // the row -> (block, row) walk of the epilogue advances by 8 rows at a time
     return g.M >= BM && g.N >= 128 && (g.K % BK) == 0 && (g.N % 4) == 0 && (g.n_per >= g.N || (g.n_per % 64) == 0) && g.m_per >= 8;
+}
+
+// LM head at hundreds of rows (bf16 operands): argmax partials per row = column tiles x 4 (layout [part][x_mpad])
+bool wh_lm_head_tile_applicable(const SkinnyArgs& a) {
+    const char* e = getenv("WH_LM_TILE_MIN_ROWS");   // (0 disables: A/B runs and the parity test flip it between contexts)
+    const int min_rows = e ? atoi(e) : 256;
+    return min_rows > 0 && a.M >= min_rows && (a.K % BK) == 0 && a.K / BK >= 4 && a.X != nullptr && a.xpart == nullptr && a.wscale == nullptr;
+}
+int wh_lm_head_tile_parts(const SkinnyArgs& a) { return ((a.N + 255) / 256) * Geo<256>::WN; }
+void wh_launch_lm_head_tile(hipStream_t s, const SkinnyArgs& a) {
+    typedef Geo<256> G;
+    const size_t sm = (size_t)G::NSLOT * G::SLOT + (size_t)BM * 2 * 4 * 5;   // ring + LayerNorm statistics ([256][2] + four quarter sums)
+    dim3 grid(((a.N + 255) / 256) * ((a.M + BM - 1) / BM));
+    wh_ensure_dyn_lds((const void*)k_lm_head_tile, sm);
+    hipLaunchKernelGGL(k_lm_head_tile, grid, dim3(512), sm, s, a);
 }
 
 void wh_launch_gemm8(hipStream_t s, bool out_f32, const GemmArgs& g) {

@@ -136,6 +136,10 @@ void wh_launch_dec_gemm(hipStream_t s, int prec, bool out_f32, const SkinnyArgs&
 void wh_launch_dec_embed(hipStream_t s, int prec, const void* tok_emb, const float* pos_emb, const int* feed, int feed_ld,
                          const int* pos_p, float* x, void* xslab, float* stats, int rows, int d, int mpad, const float* xgamma);
 void wh_launch_lm_head(hipStream_t s, int prec, const SkinnyArgs& a);
+// wh_gemm8.hip: the same contract on 256 x 256 LDS-DMA tiles for hundreds of rows (bit-identical logits; bf16 operands)
+bool wh_lm_head_tile_applicable(const SkinnyArgs& a);
+int wh_lm_head_tile_parts(const SkinnyArgs& a);
+void wh_launch_lm_head_tile(hipStream_t s, const SkinnyArgs& a);
 int wh_lm_head_parts(int prec, const SkinnyArgs& a);  // argmax partials per row written by wh_launch_lm_head, layout [part][x_mpad]
 void wh_launch_argmax_finish(hipStream_t s, int prec, const float* part_val, const int* part_idx, int n_parts, int mpad, int* pos_p,
                              int* ticket, const DecodeState& st, int B, const NextEmbed& ne);
