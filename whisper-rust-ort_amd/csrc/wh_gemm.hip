@@ -335,6 +335,10 @@ void wh_launch_gemm(hipStream_t s, int prec, bool out_f32, const GemmArgs& g) {
         wh_launch_gemm8(s, out_f32, g);
         return;
     }
+    if (g.ln_mode || g.xb_out || g.stats_out) {   // only k_gemm8 implements the LayerNorm fold: never drop it silently
+        wh_set_error("GEMM with a folded LayerNorm (M %d N %d K %d) must run on k_gemm8", g.M, g.N, g.K);
+        return;
+    }
     if (prec == WH_PREC_F32) {
         launch_gemm_t<float, float>(s, g);
     } else {

@@ -79,7 +79,9 @@ __device__ __forceinline__ void store8(bf16* p, const f32x4& a, const f32x4& b) 
 
 // ABL (tools/gemm8_ablate.hip only; 0 in the library): 1 = no MFMA (fragment reads kept), 2 = no LDS-DMA inside the loop, 32 = no W stage,
 // 4 = no epilogue, 8 = no fragment reads and no MFMA (loads + barriers only), 16 = epilogue without its global stores
-template <typename TO, int BN, int ABL = 0>
+// LN (compile-time, so that the register budget of the 128-wide geometry holds): 0 = plain epilogue (bias, channel scale);
+// 1 / 2 = consumer of a folded LayerNorm with the statistics per output row / per output column (GemmArgs::ln_mode)
+template <typename TO, int BN, int ABL = 0, int LN = 0>
 __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs g) {
     typedef Geo<BN> G;
     constexpr int TM = G::TM, TN = G::TN, NSLOT = G::NSLOT, SLOT = G::SLOT, SLOT_A = G::SLOT_A;
@@ -231,15 +233,25 @@ __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs
     TO* C = (TO*)g.C + z * g.c_zs;
     const float* R = g.R ? g.R + z * g.r_zs : nullptr;
     const long nc0 = (long)(nw0 / g.n_per) * g.c_ns + (nw0 % g.n_per);   // n_per is a multiple of 64 or >= N (checked at launch)
+    // per-column operands of this lane's 4 consecutive n per tile — LN 0: bias, channel scale; LN 1: c[n] (as bias), s[n];
+    // LN 2: mean[n], rstd[n] (bias and s are per row there)
     f32x4 pb[TN], pw[TN];
+    const float* lstat = LN ? g.ln_stat + z * g.ln_stat_zs : nullptr;
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int n = nw0 + j * 16 + fg * 4;
         pb[j] = f32x4{0, 0, 0, 0};
         pw[j] = f32x4{1, 1, 1, 1};
-        if (n < g.N && g.bias_mode == 1) {
+        if (LN == 2) {
+            if (n < g.N) {   // {mean, rstd} interleaved per column (N % 4 == 0: whole groups of four)
+                const f32x4 u0 = *reinterpret_cast<const f32x4*>(lstat + 2 * (long)n), u1 = *reinterpret_cast<const f32x4*>(lstat + 2 * (long)n + 4);
+                pb[j] = f32x4{u0[0], u0[2], u1[0], u1[2]};
+                pw[j] = f32x4{u0[1], u0[3], u1[1], u1[3]};
+            }
+        } else if (n < g.N && g.bias_mode == 1) {
             if (g.bias) pb[j] = *reinterpret_cast<const f32x4*>(g.bias + n);
-            if (g.wscale) pw[j] = *reinterpret_cast<const f32x4*>(g.wscale + n);
+            if (LN == 1) pw[j] = *reinterpret_cast<const f32x4*>(g.ln_s + n);
+            else if (g.wscale) pw[j] = *reinterpret_cast<const f32x4*>(g.wscale + n);
         }
     }
     // row-contiguous read-back: 8 lanes x 8 columns per row, 8 rows per wave-instruction
@@ -251,16 +263,23 @@ __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs
         for (int ii = 0; ii < 2; ii++) {
             const int i = pass * 2 + ii;
             const int m = mw0 + i * 16 + fl;
-            float bm = 0.0f, wmul = 1.0f;
-            if (g.bias_mode == 2 && m < g.M) {
+            float bm = 0.0f, wmul = 1.0f;   // LN 1: bm = rstd[m], wmul = mean[m];  LN 2: bm = c[m], wmul = s[m]
+            if (LN == 1) {
+                if (m < g.M) { wmul = lstat[2 * (long)m]; bm = lstat[2 * (long)m + 1]; }
+            } else if (g.bias_mode == 2 && m < g.M) {
                 if (g.bias) bm = g.bias[m];
-                if (g.wscale) wmul = g.wscale[m];
+                if (LN == 2) wmul = g.ln_s[m];
+                else if (g.wscale) wmul = g.wscale[m];
             }
 #pragma unroll
             for (int j = 0; j < TN; j++) {
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = acc[i][j][e] * (pw[j][e] * wmul) + (pb[j][e] + bm);
+                for (int e = 0; e < 4; e++) {
+                    if (LN == 1) v[e] = bm * (acc[i][j][e] - wmul * pw[j][e]) + pb[j][e];          // rstd (acc - mean s[n]) + c[n]
+                    else if (LN == 2) v[e] = pw[j][e] * (acc[i][j][e] - pb[j][e] * wmul) + bm;     // rstd[n] (acc - mean[n] s[m]) + c[m]
+                    else v[e] = acc[i][j][e] * (pw[j][e] * wmul) + (pb[j][e] + bm);
+                }
                 if (g.act == 1) {
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
@@ -274,6 +293,7 @@ __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs
 #pragma unroll
         for (int it = 0; it < EP_ROWS / 8; it++) {
             const int lr = it * 8 + r8, m = mp0 + it * 8;
+            float s1 = 0.0f, s2 = 0.0f;   // LayerNorm partial sums of this lane's 8 values (producers)
             if (m < g.M && n_st < g.N) {
                 f32x4 v0 = *reinterpret_cast<const f32x4*>(&stg[lr * EP_PITCH + c8]);
                 f32x4 v1 = *reinterpret_cast<const f32x4*>(&stg[lr * EP_PITCH + c8 + 4]);
@@ -288,6 +308,28 @@ __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs
                 if (ABL & 16) asm volatile("" :: "v"(v0), "v"(v1));   // everything but the store
                 else if (n_st + 8 <= g.N) store8(cp, v0, v1);
                 else store4(cp, v0[0], v0[1], v0[2], v0[3]);          // N % 8 == 4: the last group holds 4 valid columns
+                if constexpr (sizeof(TO) == 4) {
+                    // producer of a LayerNorm input (N % 64 == 0 and contiguous rows checked at launch): the row segment again as
+                    // bf16 — the consumer GEMMs' operand — and its contribution to the row's {sum, sum of squares}
+                    if (g.xb_out) store8((bf16*)g.xb_out + z * g.c_zs + mb * g.c_bs + mi * g.ldc + nc0 + c8, v0, v1);
+                    if (g.stats_out) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) { s1 += v0[e]; s2 += v0[e] * v0[e]; }
+#pragma unroll
+                        for (int e = 0; e < 4; e++) { s1 += v1[e]; s2 += v1[e] * v1[e]; }
+                    }
+                }
+            }
+            if constexpr (sizeof(TO) == 4) {
+                if (g.stats_out) {    // the 8 lanes of a row -> one partial per (64-column group, row): DPP only, fixed order
+                    s1 = dpp_group_sum<8>(s1);
+                    s2 = dpp_group_sum<8>(s2);
+                    if ((lane & 7) == 0 && m < g.M && n_st < g.N) {
+                        float* sp = g.stats_out + ((long)(nw0 >> 6) * g.stats_rows + m) * 2;
+                        sp[0] = s1;
+                        sp[1] = s2;
+                    }
+                }
             }
             mi += 8;
             if (mi >= g.m_per) { mi -= g.m_per; mb += 1; }
@@ -481,14 +523,14 @@ __global__ __launch_bounds__(512, 2) void k_lm_head_tile(SkinnyArgs a) {
     }
 }
 
-template <typename TO, int BN>
+template <typename TO, int BN, int LN = 0>
 void launch8(hipStream_t s, const GemmArgs& g) {
     typedef Geo<BN> G;
     const size_t sm = (size_t)G::NSLOT * G::SLOT;
     static_assert((size_t)8 * EP_ROWS * EP_PITCH * 4 <= (size_t)G::NSLOT * G::SLOT, "output staging must fit the ring");
     dim3 grid(((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM), 1, g.batch);
-    wh_ensure_dyn_lds((const void*)k_gemm8<TO, BN>, sm);
-    hipLaunchKernelGGL((k_gemm8<TO, BN>), grid, dim3(512), sm, s, g);
+    wh_ensure_dyn_lds((const void*)k_gemm8<TO, BN, 0, LN>, sm);
+    hipLaunchKernelGGL((k_gemm8<TO, BN, 0, LN>), grid, dim3(512), sm, s, g);
 }
 
 }  // namespace
@@ -497,6 +539,24 @@ bool wh_gemm8_applicable(const GemmArgs& g) {
     // N tails are handled by clamping + masking in 8-column groups (a last group of 4); the column-plane mapping needs 64-column granularity;
     // the row -> (block, row) walk of the epilogue advances by 8 rows at a time
     return g.M >= BM && g.N >= 128 && (g.K % BK) == 0 && (g.N % 4) == 0 && (g.n_per >= g.N || (g.n_per % 64) == 0) && g.m_per >= 8;
+}
+
+// {mean, rstd} per row from the producers' per-(64-column group, row) partial sums; groups are added in order (deterministic)
+__global__ __launch_bounds__(256) void k_ln_stats(const float* __restrict__ partials, int groups, long rows, float inv_d, float* __restrict__ stat) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int g0 = 0; g0 < groups; g0 += 8) {   // eight loads in flight
+        f32x2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const f32x2*>(partials + ((long)min(g0 + u, groups - 1) * rows + r) * 2);
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (g0 + u < groups) { s1 += v[u].x; s2 += v[u].y; }
+    }
+    const float mean = s1 * inv_d;
+    *reinterpret_cast<f32x2*>(stat + 2 * r) = f32x2{mean, rsqrtf(fmaxf(s2 * inv_d - mean * mean, 0.0f) + 1e-5f)};   // biased variance, eps 1e-5
 }
 
 // LM head at hundreds of rows (bf16 operands): argmax partials per row = column tiles x 4 (layout [part][x_mpad])
@@ -514,11 +574,28 @@ void wh_launch_lm_head_tile(hipStream_t s, const SkinnyArgs& a) {
     hipLaunchKernelGGL(k_lm_head_tile, grid, dim3(512), sm, s, a);
 }
 
+void wh_launch_ln_stats(hipStream_t s, const float* partials, int groups, long rows, int d, float* stat) {
+    hipLaunchKernelGGL(k_ln_stats, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, partials, groups, rows, 1.0f / (float)d, stat);
+}
+
 void wh_launch_gemm8(hipStream_t s, bool out_f32, const GemmArgs& g) {
+    if ((g.xb_out || g.stats_out) && (!out_f32 || (g.N % 64) != 0 || g.n_per < g.N || (g.m_per < g.M && g.c_bs != (long)g.m_per * g.ldc) || g.batch != 1)) {
+        wh_set_error("k_gemm8: LayerNorm-producer outputs need an f32 result with contiguous rows and N a multiple of 64");
+        return;
+    }
     // measured per shape (tools/gemm8_ablate.hip): the GELU epilogue is VALU work that a second workgroup on the CU hides
     // under its own MFMAs (fc1: 1.30 ms with BN = 128 against 1.43 ms); everything else is faster or equal with the larger
     // tile's halved L2 -> LDS traffic
     const bool wide = g.act == 0 && g.N >= 256;
+    if (g.ln_mode) {   // consumers of a folded LayerNorm: bf16 results only, no channel scale (the bf16 encoder path)
+        if (out_f32 || g.wscale || !g.ln_stat || !g.ln_s || (g.ln_mode == 1 && g.bias_mode != 1) || (g.ln_mode == 2 && (g.bias_mode != 2 || (g.N % 4) != 0))) {
+            wh_set_error("k_gemm8: unsupported LayerNorm-fold arguments (mode %d)", g.ln_mode);
+            return;
+        }
+        if (g.ln_mode == 1) { if (wide) launch8<bf16, 256, 1>(s, g); else launch8<bf16, 128, 1>(s, g); }
+        else { if (wide) launch8<bf16, 256, 2>(s, g); else launch8<bf16, 128, 2>(s, g); }
+        return;
+    }
     if (out_f32) { if (wide) launch8<float, 256>(s, g); else launch8<float, 128>(s, g); }
     else { if (wide) launch8<bf16, 256>(s, g); else launch8<bf16, 128>(s, g); }
 }

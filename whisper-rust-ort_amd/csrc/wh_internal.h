@@ -17,6 +17,10 @@ struct EncLayerDev {
     float *qk_sc = nullptr, *v_sc = nullptr, *o_sc = nullptr, *fc1_sc = nullptr, *fc2_sc = nullptr;
     // ... and these the raw e4m3 codes [N][K] (one byte each) for the fp8-MFMA GEMMs (wh_gemm8_mx.hip)
     void *qk_w8 = nullptr, *v_w8 = nullptr, *fc1_w8 = nullptr, *fc2_w8 = nullptr;
+    // WH_PREC_BF16, LayerNorm folded into the consumer GEMMs (wh_gemm8.hip, run_encoder's fold path): W (.) gamma in bf16,
+    // s[n] = sum_k of the stored values, c[n] = bias[n] + sum_k beta[k] W[n][k]
+    void *qk_wf = nullptr, *v_wf = nullptr, *fc1_wf = nullptr;
+    float *qk_s = nullptr, *qk_c = nullptr, *v_s = nullptr, *v_c = nullptr, *fc1_s = nullptr, *fc1_c = nullptr;
 };
 struct DecLayerDev {
     void *qkv_w, *o_w, *cq_w, *co_w, *fc1_w, *fc2_w;
@@ -47,6 +51,8 @@ struct wh_model {
     float *enc_ln_w = nullptr, *enc_ln_b = nullptr, *dec_ln_w = nullptr, *dec_ln_b = nullptr;
     float* cross_kv_sc = nullptr;  // WH_PREC_FP8: scales of the cross K/V projection rows [Ld][2][d]
     void* cross_kv_w8 = nullptr;   // WH_PREC_FP8: the same rows as raw e4m3 codes
+    void* cross_kv_wf = nullptr;   // WH_PREC_BF16: the same rows with the encoder's final LayerNorm folded in (+ s, c)
+    float *cross_kv_s = nullptr, *cross_kv_c = nullptr;
     void* lm_w = nullptr;  // tied embedding ⊙ final-LN γ (LM head operand); WH_PREC_FP8: the embedding itself (γ on the activation side)
     float *lm_s = nullptr, *lm_c = nullptr;
     std::vector<EncLayerDev> enc;
@@ -124,6 +130,12 @@ struct wh_ctx {
     unsigned char *xn8 = nullptr, *xn8_sc = nullptr;   // LayerNorm outputs [B*S][d]
     unsigned char *h8 = nullptr, *h8_sc = nullptr;     // GELU(fc1) [B*S][ffn]
     float* enc_out_f32 = nullptr;  // [B][S][d] f32 (API output)
+    // WH_PREC_BF16 with the encoder LayerNorms folded into their consumer GEMMs (enc_fold): the residual stream again as bf16
+    // (written by the producing GEMM's epilogue; the consumers' operand), the producers' partial sums and {mean, rstd} per row
+    bool enc_fold = false;
+    void* xb = nullptr;            // [B][S][d] bf16
+    float* enc_part = nullptr;     // [d/64][B*S][2]
+    float* enc_stat = nullptr;     // [B*S][2]
     int ldv = 0;
     void* cross_kv = nullptr;   // [Ld][2][B][S][d]
     void* cross_kv8 = nullptr;  // WH_PREC_FP8: the same planes as e4m3 codes (cross_kv is then the bf16 staging copy)

@@ -34,6 +34,19 @@ struct GemmArgs {
     const unsigned char* w_sc8 = nullptr;
     long a_sc_zs = 0, w_sc_zs = 0;
     unsigned char* c_sc = nullptr;   // MX output: block exponents of C (C itself receives the codes), layout [row][4][wh_mx_nkp(N)]
+    // LayerNorm folded around the GEMM (wh_gemm8.hip, bf16 encoder path): LN(x) W^T = rstd (x (gamma . W)^T - mean s) + c.
+    //  consumer: y = rstd_i (acc - mean_i ln_s) + bias with {mean_i, rstd_i} = ln_stat[2 i .. 2 i + 1], i = the output ROW m
+    //            (ln_mode 1: ln_s per column n, indexed like bias_mode 1) or the output COLUMN n (ln_mode 2: the per-clip V^T
+    //            product, whose columns are the keys; ln_s per row m, like bias_mode 2; ln_stat advances by ln_stat_zs per batch)
+    const float* ln_stat = nullptr;
+    long ln_stat_zs = 0;
+    const float* ln_s = nullptr;
+    int ln_mode = 0;
+    //  producer of a LayerNorm input (contiguous f32 rows, out_f32): besides C also write the rows as bf16 (xb_out, C's
+    //            addressing) and, per (64-column group, row), the partial sums {sum v, sum v^2} into stats_out[group][stats_rows][2]
+    void* xb_out = nullptr;
+    float* stats_out = nullptr;
+    long stats_rows = 0;
 };
 
 struct SkinnyArgs {
@@ -117,6 +130,8 @@ void wh_launch_mel_tokens(hipStream_t s, const float* src, long src_clip_stride,
 void wh_launch_gemm(hipStream_t s, int prec, bool out_f32, const GemmArgs& g);
 // wh_gemm8.hip: the 8-wave LDS-DMA kernel (bf16 operands) for problems with at least one full 256 x 128 tile
 bool wh_gemm8_applicable(const GemmArgs& g);
+// {mean, rstd} per row from the producers' partial sums: stat[row][2] <- partials[groups][rows][2] (groups added in order)
+void wh_launch_ln_stats(hipStream_t s, const float* partials, int groups, long rows, int d, float* stat);
 void wh_launch_gemm8(hipStream_t s, bool out_f32, const GemmArgs& g);
 // MX block exponents of a [rows][K] operand: [row][4][nkp] bytes, nkp = K-steps of 128 rounded up to a multiple of 4 (from 4 on)
 // so that the bytes of 16 consecutive K-steps are four aligned dwords

@@ -626,6 +626,33 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
             c_out[r] = (float)cacc;
         }
     };
+    // WH_PREC_BF16: the encoder's LayerNorms folded into the GEMMs they feed (Q|K, V, fc1, and — the final one — the stacked
+    // cross-attention K/V projection); the plain matrices stay for contexts that do not take the fold path
+    struct EncFold { size_t qk, qks, qkc, v, vs, vc, f1, f1s, f1c; };
+    std::vector<EncFold> ef(c.enc_layers);
+    const bool enc_fold = m->prec == WH_PREC_BF16;
+    if (enc_fold) {
+        for (int i = 0; i < c.enc_layers; i++) {
+            std::string p = e + ".layers." + std::to_string(i);
+            EncFold& x = ef[i];
+            const float *g1 = T(p + ".self_attn_layer_norm.weight"), *b1 = T(p + ".self_attn_layer_norm.bias");
+            const float *g2 = T(p + ".final_layer_norm.weight"), *b2 = T(p + ".final_layer_norm.bias");
+            std::vector<float> sv(std::max(2 * d, F)), cv(std::max(2 * d, F));
+            x.qk = st.reserve(2 * d * d * m->esz);
+            fold_ln(x.qk, 0, T(p + ".self_attn.q_proj.weight"), d, d, qs, g1, b1, T(p + ".self_attn.q_proj.bias"), sv.data(), cv.data());
+            fold_ln(x.qk, d, T(p + ".self_attn.k_proj.weight"), d, d, 1.0f, g1, b1, nullptr, sv.data() + d, cv.data() + d);
+            x.qks = st.put_f32(sv.data(), 2 * d);
+            x.qkc = st.put_f32(cv.data(), 2 * d);
+            x.v = st.reserve(d * d * m->esz);
+            fold_ln(x.v, 0, T(p + ".self_attn.v_proj.weight"), d, d, 1.0f, g1, b1, T(p + ".self_attn.v_proj.bias"), sv.data(), cv.data());
+            x.vs = st.put_f32(sv.data(), d);
+            x.vc = st.put_f32(cv.data(), d);
+            x.f1 = st.reserve(F * d * m->esz);
+            fold_ln(x.f1, 0, T(p + ".fc1.weight"), F, d, 1.0f, g2, b2, T(p + ".fc1.bias"), sv.data(), cv.data());
+            x.f1s = st.put_f32(sv.data(), F);
+            x.f1c = st.put_f32(cv.data(), F);
+        }
+    }
     std::vector<DecOff> dof(c.dec_layers);
     const size_t Ld = c.dec_layers;
     size_t o_ckv = st.reserve(Ld * 2 * d * d * m->esz);
@@ -720,6 +747,20 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
         x.l3b = st.put_f32(T(p + ".final_layer_norm.bias"), d);
     }
     size_t o_ckvb = st.put_f32(ckvb.data(), ckvb.size());
+    size_t o_ckvf = NONE, o_ckvs = NONE, o_ckvc = NONE;
+    if (enc_fold) {   // the encoder's final LayerNorm folded into the stacked K/V projection rows (k_proj has no bias)
+        o_ckvf = st.reserve(Ld * 2 * d * d * m->esz);
+        std::vector<float> sv(Ld * 2 * d), cv(Ld * 2 * d);
+        const float *ge = T(e + ".layer_norm.weight"), *be = T(e + ".layer_norm.bias");
+        for (size_t i = 0; i < Ld; i++) {
+            std::string p = dd + ".layers." + std::to_string(i);
+            fold_ln(o_ckvf, (i * 2 + 0) * d, T(p + ".encoder_attn.k_proj.weight"), d, d, 1.0f, ge, be, nullptr, sv.data() + (i * 2 + 0) * d, cv.data() + (i * 2 + 0) * d);
+            fold_ln(o_ckvf, (i * 2 + 1) * d, T(p + ".encoder_attn.v_proj.weight"), d, d, 1.0f, ge, be, T(p + ".encoder_attn.v_proj.bias"), sv.data() + (i * 2 + 1) * d,
+                    cv.data() + (i * 2 + 1) * d);
+        }
+        o_ckvs = st.put_f32(sv.data(), sv.size());
+        o_ckvc = st.put_f32(cv.data(), cv.size());
+    }
     size_t o_ckvsc = f8 ? st.put_f32(ckvsc.data(), ckvsc.size()) : NONE;
     size_t o_ckv8 = f8 ? st.put_bytes(ckv8.data(), ckv8.size()) : NONE;
     size_t o_dlnw = st.put_f32(T(dd + ".layer_norm.weight"), d), o_dlnb = st.put_f32(T(dd + ".layer_norm.bias"), d);
@@ -779,6 +820,12 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
                                 PF(x.f2b), PF(x.l1w), PF(x.l1b), PF(x.l2w), PF(x.l2b)};
         if (f8) { m->enc[i].qk_w8 = P(x.qk8); m->enc[i].v_w8 = P(x.v8); m->enc[i].fc1_w8 = P(x.f18); m->enc[i].fc2_w8 = P(x.f28); }
         if (f8) { m->enc[i].qk_sc = PF(x.qksc); m->enc[i].v_sc = PF(x.vsc); m->enc[i].o_sc = PF(x.osc); m->enc[i].fc1_sc = PF(x.f1sc); m->enc[i].fc2_sc = PF(x.f2sc); }
+        if (enc_fold) {
+            const EncFold& y = ef[i];
+            m->enc[i].qk_wf = P(y.qk); m->enc[i].qk_s = PF(y.qks); m->enc[i].qk_c = PF(y.qkc);
+            m->enc[i].v_wf = P(y.v); m->enc[i].v_s = PF(y.vs); m->enc[i].v_c = PF(y.vc);
+            m->enc[i].fc1_wf = P(y.f1); m->enc[i].fc1_s = PF(y.f1s); m->enc[i].fc1_c = PF(y.f1c);
+        }
     }
     m->enc_ln_w = PF(o_elnw); m->enc_ln_b = PF(o_elnb);
     m->tok_emb = P(o_tok); m->dec_pos = PF(o_dpos);
@@ -795,6 +842,7 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     }
     m->cross_kv_w = P(o_ckv); m->cross_kv_b = PF(o_ckvb);
     if (f8) { m->cross_kv_sc = PF(o_ckvsc); m->cross_kv_w8 = P(o_ckv8); }
+    if (enc_fold) { m->cross_kv_wf = P(o_ckvf); m->cross_kv_s = PF(o_ckvs); m->cross_kv_c = PF(o_ckvc); }
     m->dec_ln_w = PF(o_dlnw); m->dec_ln_b = PF(o_dlnb);
     m->lm_w = P(o_lmw); m->lm_s = PF(o_lms); m->lm_c = PF(o_lmc);
     m->mel_tw = (double*)P(o_tw); m->mel_win = PF(o_win); m->mel_fbT = PF(o_fb);
