@@ -1353,12 +1353,27 @@ void wh_launch_dec_self_attn(hipStream_t s, int prec, const void* qkv, void* kc,
         hipLaunchKernelGGL(k_dec_self_attn<bf16>, grid, dim3(64), 0, s, (const bf16*)qkv, (bf16*)kc, (bf16*)vc, (bf16*)out, pos_p, d, n_heads, tc, mpad);
 }
 
+// Occupancy cap of the cross-attention stream.  With more than two workgroups resident per CU (1024 clips = 4 per CU) every one
+// keeps 32 KB of K/V rows in flight and the memory system queues far more requests than the ~7 MB its latency x bandwidth
+// needs; measured at 1024 clips (profiles/r03_cross_attn_occupancy.txt): 474.5 us per launch with 4 resident workgroups per
+// CU, 493.4 with 3, 464.2 with 2, 477.0 with 1.  The cap is an LDS reservation: a launch with more than 2 x 256 workgroups
+// asks for 72 KB of dynamic LDS per workgroup (the kernels use only their own first bytes), so two fit a CU's 160 KB and a
+// third does not.  WH_CROSS_WGS_PER_CU=0 removes the cap, 1 reserves for one workgroup per CU.  Results do not depend on it.
+size_t wh_cross_lds_reserve(long total_wgs, size_t own_bytes) {
+    static const int cap = [] { const char* e = getenv("WH_CROSS_WGS_PER_CU"); return e ? atoi(e) : 2; }();
+    if (cap <= 0 || cap > 2 || total_wgs <= (long)cap * 256) return own_bytes;
+    const size_t target = cap == 1 ? (size_t)150 * 1024 : (size_t)72 * 1024;
+    return own_bytes > target ? own_bytes : target;
+}
+
 void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void* ck, const void* cv, float* part,
                               float* ml, int S, int d, int n_heads, int splits, int B, void* out, int mpad, bool stream_nt) {
     dim3 grid(splits, B);
-    const size_t sm = sizeof(float) * ((size_t)8 * n_heads + 4 * (size_t)d);
-#define WH_CA1(T_, N_, U_, NT_) hipLaunchKernelGGL((k_dec_cross_attn<T_, N_, U_, NT_>), grid, dim3(256), sm, s, (const T_*)q, (const T_*)ck, \
-                                             (const T_*)cv, part, ml, S, d, n_heads, splits, (T_*)(splits == 1 ? out : nullptr), mpad)
+    const long wgs = (long)splits * B * ((prec != WH_PREC_F32 && d > 512 && d % 256 == 0) ? d / 256 : 1);
+    const size_t sm = wh_cross_lds_reserve(wgs, sizeof(float) * ((size_t)8 * n_heads + 4 * (size_t)d));
+#define WH_CA1(T_, N_, U_, NT_) do { set_max_smem(k_dec_cross_attn<T_, N_, U_, NT_>, sm);                                                 \
+                                     hipLaunchKernelGGL((k_dec_cross_attn<T_, N_, U_, NT_>), grid, dim3(256), sm, s, (const T_*)q, (const T_*)ck, \
+                                             (const T_*)cv, part, ml, S, d, n_heads, splits, (T_*)(splits == 1 ? out : nullptr), mpad); } while (0)
 #define WH_CA(T_, N_, U_) do { if (stream_nt) WH_CA1(T_, N_, U_, true); else WH_CA1(T_, N_, U_, false); } while (0)
     if (prec == WH_PREC_F32) {
         const int nch = (d / 4 + 63) / 64;  // f32: 4 elements per chunk
@@ -1367,12 +1382,14 @@ void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void
         else WH_CA(float, 5, 1);
     } else {
         const int nch = (d / 8 + 63) / 64;
-        if (nch == 1) { if (wh_dbg_cross_unroll == 8) WH_CA(bf16, 1, 8); else WH_CA(bf16, 1, 4); }
+        static const int unroll_env = [] { const char* e = getenv("WH_CROSS_UNROLL"); return e ? atoi(e) : 0; }();   // (A/B runs)
+        if (nch == 1) { if ((unroll_env ? unroll_env : wh_dbg_cross_unroll) == 8) WH_CA(bf16, 1, 8); else WH_CA(bf16, 1, 4); }
         else if (d % 256 == 0 && getenv("WH_CROSS_ALLHEADS") == nullptr) {   // wide models: one workgroup per 256-column group
             dim3 g3(splits, B, d / 256);
             bf16* o = (bf16*)(splits == 1 ? out : nullptr);
-            if (stream_nt) hipLaunchKernelGGL((k_dec_cross_attn_cg<4, true>), g3, dim3(256), 0, s, (const bf16*)q, (const bf16*)ck, (const bf16*)cv, part, ml, S, d, n_heads, splits, o, mpad);
-            else hipLaunchKernelGGL((k_dec_cross_attn_cg<4, false>), g3, dim3(256), 0, s, (const bf16*)q, (const bf16*)ck, (const bf16*)cv, part, ml, S, d, n_heads, splits, o, mpad);
+            const size_t smcg = wh_cross_lds_reserve(wgs, 12 * 1024) - 12 * 1024;   // (the kernel's own ~10 KB are static: only the reserve is dynamic)
+            if (stream_nt) { set_max_smem(k_dec_cross_attn_cg<4, true>, smcg); hipLaunchKernelGGL((k_dec_cross_attn_cg<4, true>), g3, dim3(256), smcg, s, (const bf16*)q, (const bf16*)ck, (const bf16*)cv, part, ml, S, d, n_heads, splits, o, mpad); }
+            else { set_max_smem(k_dec_cross_attn_cg<4, false>, smcg); hipLaunchKernelGGL((k_dec_cross_attn_cg<4, false>), g3, dim3(256), smcg, s, (const bf16*)q, (const bf16*)ck, (const bf16*)cv, part, ml, S, d, n_heads, splits, o, mpad); }
         } else WH_CA(bf16, 3, 2);
     }
 #undef WH_CA

@@ -243,7 +243,11 @@ __global__ __launch_bounds__(256) void k_dec_cross_attn8(const bf16* __restrict_
 template <int KPI, int NCH, int UNROLL>
 void launch_ca8(hipStream_t s, const void* q, const void* ck, const void* cv, const float* amax_k, const float* amax_v, float* part,
                 float* ml, int S, int d, int n_heads, int splits, int B, void* out, int mpad, bool stream_nt) {
-    const size_t sm = sizeof(float) * ((size_t)2 * 4 * KPI * n_heads + (size_t)4 * KPI * d);
+    const size_t sm = wh_cross_lds_reserve((long)splits * B, sizeof(float) * ((size_t)2 * 4 * KPI * n_heads + (size_t)4 * KPI * d));
+    if (sm > 48 * 1024) {
+        wh_ensure_dyn_lds((const void*)k_dec_cross_attn8<KPI, NCH, UNROLL, true>, sm);
+        wh_ensure_dyn_lds((const void*)k_dec_cross_attn8<KPI, NCH, UNROLL, false>, sm);
+    }
     if (stream_nt)
         hipLaunchKernelGGL((k_dec_cross_attn8<KPI, NCH, UNROLL, true>), dim3(splits, B), dim3(256), sm, s, (const bf16*)q,
                            (const unsigned char*)ck, (const unsigned char*)cv, amax_k, amax_v, part, ml, S, d, n_heads, splits,

@@ -165,6 +165,10 @@ void wh_launch_dec_self_attn(hipStream_t s, int prec, const void* qkv, void* kc,
 void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void* ck, const void* cv, float* part,
                               float* ml, int S, int d, int n_heads, int splits, int B, void* out, int mpad, bool stream_nt);
 
+// dynamic LDS to request for a cross-attention launch of total_wgs workgroups whose kernel needs own_bytes: caps the resident
+// workgroups per CU at two for large launches (wh_decode.hip)
+size_t wh_cross_lds_reserve(long total_wgs, size_t own_bytes);
+
 // WH_PREC_FP8 (wh_fp8.hip)
 void wh_launch_kv_quant(hipStream_t s, const void* kv_bf16, unsigned* amax, void* kv8, long planes_x_clips, int S, int d,
                         int n_heads);
