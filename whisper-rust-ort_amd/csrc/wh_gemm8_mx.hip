@@ -70,7 +70,120 @@ __device__ __forceinline__ float quad_max(float v) {
     return v;
 }
 
+// ---- epilogue (k_gemm8's): 32 rows per wave and pass through the wave's own 8.5 KiB of the idle ring; shared by both tile geometries
 struct MxOut {};   // tag: C = e4m3 codes + block exponents
+template <typename TO, int TM, int TN>
+__device__ __forceinline__ void mx_epilogue(const GemmArgs& g, f32x4 (&acc)[TM][TN], char* smem, int wave, int lane, int mw0, int nw0, long z) {
+    const int fl = lane & 15, fg = lane >> 4;
+    float* stg = reinterpret_cast<float*>(smem) + wave * (EP_ROWS * EP_PITCH);
+    constexpr bool MX = __is_same(TO, MxOut);
+    typedef typename std::conditional<MX, unsigned char, TO>::type TC;
+    TC* C = (TC*)g.C + z * g.c_zs;
+    const float* R = g.R ? g.R + z * g.r_zs : nullptr;
+    const long nc0 = (long)(nw0 / g.n_per) * g.c_ns + (nw0 % g.n_per);
+    f32x4 pb[TN], pw[TN];
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = nw0 + j * 16 + fg * 4;
+        pb[j] = f32x4{0, 0, 0, 0};
+        pw[j] = f32x4{1, 1, 1, 1};
+        if (n < g.N && g.bias_mode == 1) {
+            if (g.bias) pb[j] = *reinterpret_cast<const f32x4*>(g.bias + n);
+            if (g.wscale) pw[j] = *reinterpret_cast<const f32x4*>(g.wscale + n);
+        }
+    }
+    const int c8 = (lane & 7) * 8, r8 = lane >> 3;
+    const int n_st = nw0 + c8;
+#pragma unroll
+    for (int pass = 0; pass < TM / 2; pass++) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ii++) {
+            const int i = pass * 2 + ii;
+            const int m = mw0 + i * 16 + fl;
+            float bm = 0.0f, wmul = 1.0f;
+            if (g.bias_mode == 2 && m < g.M) {
+                if (g.bias) bm = g.bias[m];
+                if (g.wscale) wmul = g.wscale[m];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = acc[i][j][e] * (pw[j][e] * wmul) + (pb[j][e] + bm);
+                if (g.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
+                }
+                *reinterpret_cast<f32x4*>(&stg[(ii * 16 + fl) * EP_PITCH + j * 16 + fg * 4]) = f32x4{v[0], v[1], v[2], v[3]};
+            }
+        }
+        if constexpr (MX) {
+            // MX output (the GELU activations that feed fc2): 16 columns per lane -> a lane pair owns one 32-column block and
+            // a lane stores 16 bytes of codes; exponent of a block from its largest magnitude (byte = E - 8, + 1 when the
+            // mantissa exceeds 1.75: the block maximum then maps into (224, 448]), codes = e4m3(value * 2^-e).
+            // N % 128 == 0 and contiguous rows are checked at launch.
+            const int c16 = (lane & 3) * 16, r16 = lane >> 2;
+#pragma unroll
+            for (int it = 0; it < EP_ROWS / 16; it++) {
+                const int lr = it * 16 + r16, m = mw0 + pass * EP_ROWS + lr, n = nw0 + c16;
+                f32x4 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) q[u] = *reinterpret_cast<const f32x4*>(&stg[lr * EP_PITCH + c16 + 4 * u]);
+                float am = 0.0f;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) am = fmaxf(am, fabsf(q[u][e]));
+                am = fmaxf(am, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, am), 0xB1, 0xF, 0xF, true)));  // lane ^ 1
+                const unsigned ab = __float_as_uint(am);
+                const int eb = max(0, (int)((ab >> 23) & 0xFF) - 8 + (int)((ab & 0x7FFFFF) > 0x600000));
+                const float inv = __uint_as_float((unsigned)(254 - eb) << 23);
+                i32x4 pk;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    int t = __builtin_amdgcn_cvt_pk_fp8_f32(q[u][0] * inv, q[u][1] * inv, 0, false);
+                    pk[u] = __builtin_amdgcn_cvt_pk_fp8_f32(q[u][2] * inv, q[u][3] * inv, t, true);
+                }
+                if (m < g.M && n < g.N) {
+                    *reinterpret_cast<i32x4*>(C + (long)m * g.ldc + n) = pk;
+                    if ((lane & 1) == 0) {
+                        const int blk = n >> 5;
+                        g.c_sc[((long)m * 4 + (blk & 3)) * wh_mx_nkp(g.N) + (blk >> 2)] = (unsigned char)eb;
+                    }
+                }
+            }
+        } else {
+            const int mp0 = mw0 + pass * EP_ROWS + r8;
+            long mb = mp0 / g.m_per, mi = mp0 % g.m_per;
+#pragma unroll
+            for (int it = 0; it < EP_ROWS / 8; it++) {
+                const int lr = it * 8 + r8, m = mp0 + it * 8;
+                if (m < g.M && n_st < g.N) {
+                    f32x4 v0 = *reinterpret_cast<const f32x4*>(&stg[lr * EP_PITCH + c8]);
+                    f32x4 v1 = *reinterpret_cast<const f32x4*>(&stg[lr * EP_PITCH + c8 + 4]);
+                    if (R) {
+                        const float* rp = R + mb * g.r_bs + mi * g.ldr + n_st;
+                        v0 += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp));
+                        v1 += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp + 4));
+                    }
+                    TC* cp = C + mb * g.c_bs + mi * g.ldc + nc0 + c8;
+                    if (n_st + 8 <= g.N) {
+                        if constexpr (sizeof(TC) == 4) {
+                            *reinterpret_cast<f32x4*>(cp) = v0;
+                            *reinterpret_cast<f32x4*>(cp + 4) = v1;
+                        } else {
+                            *reinterpret_cast<bf16x8*>(cp) = bf16x8{(bf16)v0[0], (bf16)v0[1], (bf16)v0[2], (bf16)v0[3], (bf16)v1[0], (bf16)v1[1], (bf16)v1[2], (bf16)v1[3]};
+                        }
+                    } else {
+                        store4(cp, v0[0], v0[1], v0[2], v0[3]);   // N % 8 == 4: the last group holds 4 valid columns
+                    }
+                }
+                mi += 8;
+                if (mi >= g.m_per) { mi -= g.m_per; mb += 1; }
+            }
+        }
+    }
+}
 
 template <typename TO>
 __global__ __launch_bounds__(512, 2) void k_gemm8_mx(GemmArgs g) {
@@ -182,116 +295,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8_mx(GemmArgs g) {
         if ((kt & (MAX_NK - 1)) == MAX_NK - 1 && kt + 1 < nk) load_segment((kt + 1) / MAX_NK);   // next segment's exponents
     }
     __builtin_amdgcn_s_barrier();   // every wave is done with the ring: it becomes the output staging area
-
-    // ---- epilogue (k_gemm8's): 32 rows per wave and pass through the wave's own 8.5 KiB of the idle ring ------------------
-    float* stg = reinterpret_cast<float*>(smem) + wave * (EP_ROWS * EP_PITCH);
-    constexpr bool MX = __is_same(TO, MxOut);
-    typedef typename std::conditional<MX, unsigned char, TO>::type TC;
-    TC* C = (TC*)g.C + z * g.c_zs;
-    const float* R = g.R ? g.R + z * g.r_zs : nullptr;
-    const long nc0 = (long)(nw0 / g.n_per) * g.c_ns + (nw0 % g.n_per);
-    f32x4 pb[TN], pw[TN];
-#pragma unroll
-    for (int j = 0; j < TN; j++) {
-        const int n = nw0 + j * 16 + fg * 4;
-        pb[j] = f32x4{0, 0, 0, 0};
-        pw[j] = f32x4{1, 1, 1, 1};
-        if (n < g.N && g.bias_mode == 1) {
-            if (g.bias) pb[j] = *reinterpret_cast<const f32x4*>(g.bias + n);
-            if (g.wscale) pw[j] = *reinterpret_cast<const f32x4*>(g.wscale + n);
-        }
-    }
-    const int c8 = (lane & 7) * 8, r8 = lane >> 3;
-    const int n_st = nw0 + c8;
-#pragma unroll
-    for (int pass = 0; pass < TM / 2; pass++) {
-#pragma unroll
-        for (int ii = 0; ii < 2; ii++) {
-            const int i = pass * 2 + ii;
-            const int m = mw0 + i * 16 + fl;
-            float bm = 0.0f, wmul = 1.0f;
-            if (g.bias_mode == 2 && m < g.M) {
-                if (g.bias) bm = g.bias[m];
-                if (g.wscale) wmul = g.wscale[m];
-            }
-#pragma unroll
-            for (int j = 0; j < TN; j++) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = acc[i][j][e] * (pw[j][e] * wmul) + (pb[j][e] + bm);
-                if (g.act == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
-                }
-                *reinterpret_cast<f32x4*>(&stg[(ii * 16 + fl) * EP_PITCH + j * 16 + fg * 4]) = f32x4{v[0], v[1], v[2], v[3]};
-            }
-        }
-        if constexpr (MX) {
-            // MX output (the GELU activations that feed fc2): 16 columns per lane -> a lane pair owns one 32-column block and
-            // a lane stores 16 bytes of codes; exponent of a block from its largest magnitude (byte = E - 8, + 1 when the
-            // mantissa exceeds 1.75: the block maximum then maps into (224, 448]), codes = e4m3(value * 2^-e).
-            // N % 128 == 0 and contiguous rows are checked at launch.
-            const int c16 = (lane & 3) * 16, r16 = lane >> 2;
-#pragma unroll
-            for (int it = 0; it < EP_ROWS / 16; it++) {
-                const int lr = it * 16 + r16, m = mw0 + pass * EP_ROWS + lr, n = nw0 + c16;
-                f32x4 q[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) q[u] = *reinterpret_cast<const f32x4*>(&stg[lr * EP_PITCH + c16 + 4 * u]);
-                float am = 0.0f;
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-#pragma unroll
-                    for (int e = 0; e < 4; e++) am = fmaxf(am, fabsf(q[u][e]));
-                am = fmaxf(am, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, am), 0xB1, 0xF, 0xF, true)));  // lane ^ 1
-                const unsigned ab = __float_as_uint(am);
-                const int eb = max(0, (int)((ab >> 23) & 0xFF) - 8 + (int)((ab & 0x7FFFFF) > 0x600000));
-                const float inv = __uint_as_float((unsigned)(254 - eb) << 23);
-                i32x4 pk;
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    int t = __builtin_amdgcn_cvt_pk_fp8_f32(q[u][0] * inv, q[u][1] * inv, 0, false);
-                    pk[u] = __builtin_amdgcn_cvt_pk_fp8_f32(q[u][2] * inv, q[u][3] * inv, t, true);
-                }
-                if (m < g.M && n < g.N) {
-                    *reinterpret_cast<i32x4*>(C + (long)m * g.ldc + n) = pk;
-                    if ((lane & 1) == 0) {
-                        const int blk = n >> 5;
-                        g.c_sc[((long)m * 4 + (blk & 3)) * wh_mx_nkp(g.N) + (blk >> 2)] = (unsigned char)eb;
-                    }
-                }
-            }
-        } else {
-            const int mp0 = mw0 + pass * EP_ROWS + r8;
-            long mb = mp0 / g.m_per, mi = mp0 % g.m_per;
-#pragma unroll
-            for (int it = 0; it < EP_ROWS / 8; it++) {
-                const int lr = it * 8 + r8, m = mp0 + it * 8;
-                if (m < g.M && n_st < g.N) {
-                    f32x4 v0 = *reinterpret_cast<const f32x4*>(&stg[lr * EP_PITCH + c8]);
-                    f32x4 v1 = *reinterpret_cast<const f32x4*>(&stg[lr * EP_PITCH + c8 + 4]);
-                    if (R) {
-                        const float* rp = R + mb * g.r_bs + mi * g.ldr + n_st;
-                        v0 += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp));
-                        v1 += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp + 4));
-                    }
-                    TC* cp = C + mb * g.c_bs + mi * g.ldc + nc0 + c8;
-                    if (n_st + 8 <= g.N) {
-                        if constexpr (sizeof(TC) == 4) {
-                            *reinterpret_cast<f32x4*>(cp) = v0;
-                            *reinterpret_cast<f32x4*>(cp + 4) = v1;
-                        } else {
-                            *reinterpret_cast<bf16x8*>(cp) = bf16x8{(bf16)v0[0], (bf16)v0[1], (bf16)v0[2], (bf16)v0[3], (bf16)v1[0], (bf16)v1[1], (bf16)v1[2], (bf16)v1[3]};
-                        }
-                    } else {
-                        store4(cp, v0[0], v0[1], v0[2], v0[3]);   // N % 8 == 4: the last group holds 4 valid columns
-                    }
-                }
-                mi += 8;
-                if (mi >= g.m_per) { mi -= g.m_per; mb += 1; }
-            }
-        }
-    }
+    mx_epilogue<TO, TM, TN>(g, acc, smem, wave, lane, mw0, nw0, z);
 }
 
 // ---- LayerNorm with MX output: e4m3 codes [rows][d] + block exponents [rows][4][d/128]; one wave per row --------------
