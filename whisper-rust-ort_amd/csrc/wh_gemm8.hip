@@ -254,23 +254,56 @@ __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs
             else if (g.wscale) pw[j] = *reinterpret_cast<const f32x4*>(g.wscale + n);
         }
     }
+    // per-ROW operands of all of this lane's TM rows, requested together (one round trip instead of one per 16-row tile):
+    // LN 1: rowa = mean[m], rowb = rstd[m];  per-row bias (bias_mode 2): rowb = bias[m] / c[m], rowa = channel scale or (LN 2) s[m]
+    float rowa[TM], rowb[TM];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int m = min(mw0 + i * 16 + fl, g.M - 1);
+        rowa[i] = LN == 1 ? 0.0f : 1.0f;
+        rowb[i] = LN == 1 ? 1.0f : 0.0f;
+        if (LN == 1) {
+            typedef __attribute__((ext_vector_type(2))) float f32x2;
+            const f32x2 st = *reinterpret_cast<const f32x2*>(lstat + 2 * (long)m);
+            rowa[i] = st.x;
+            rowb[i] = st.y;
+        } else if (g.bias_mode == 2) {
+            if (g.bias) rowb[i] = g.bias[m];
+            if (LN == 2) rowa[i] = g.ln_s[m];
+            else if (g.wscale) rowa[i] = g.wscale[m];
+        }
+    }
     // row-contiguous read-back: 8 lanes x 8 columns per row, 8 rows per wave-instruction
     const int c8 = (lane & 7) * 8, r8 = lane >> 3;
     const int n_st = nw0 + c8;
 #pragma unroll
     for (int pass = 0; pass < TM / 2; pass++) {
+        // the residual rows of this pass, requested before its staging writes: four independent loads in flight under the
+        // VALU / LDS work below instead of one memory round trip per 8-row group (each behind the previous group's store)
+        // (256-wide geometry only: the 128-wide one runs two workgroups per CU on a 128-register budget that has no room for it)
+        constexpr bool RHOIST = BN == 256;
+        f32x4 rr0[RHOIST ? EP_ROWS / 8 : 1], rr1[RHOIST ? EP_ROWS / 8 : 1];
+        if (RHOIST && R) {
+            const int mq0 = mw0 + pass * EP_ROWS + r8;
+            long qb = mq0 / g.m_per, qi = mq0 % g.m_per;
+#pragma unroll
+            for (int it = 0; it < EP_ROWS / 8; it++) {
+                rr0[it] = f32x4{0, 0, 0, 0};
+                rr1[it] = f32x4{0, 0, 0, 0};
+                if (mq0 + it * 8 < g.M && n_st < g.N) {
+                    const float* rp = R + qb * g.r_bs + qi * g.ldr + n_st;
+                    rr0[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp));  // read once
+                    rr1[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp + 4));
+                }
+                qi += 8;
+                if (qi >= g.m_per) { qi -= g.m_per; qb += 1; }
+            }
+        }
 #pragma unroll
         for (int ii = 0; ii < 2; ii++) {
             const int i = pass * 2 + ii;
             const int m = mw0 + i * 16 + fl;
-            float bm = 0.0f, wmul = 1.0f;   // LN 1: bm = rstd[m], wmul = mean[m];  LN 2: bm = c[m], wmul = s[m]
-            if (LN == 1) {
-                if (m < g.M) { wmul = lstat[2 * (long)m]; bm = lstat[2 * (long)m + 1]; }
-            } else if (g.bias_mode == 2 && m < g.M) {
-                if (g.bias) bm = g.bias[m];
-                if (LN == 2) wmul = g.ln_s[m];
-                else if (g.wscale) wmul = g.wscale[m];
-            }
+            const float bm = rowb[i], wmul = rowa[i];   // LN 1: bm = rstd[m], wmul = mean[m];  LN 2: bm = c[m], wmul = s[m]
 #pragma unroll
             for (int j = 0; j < TN; j++) {
                 float v[4];
@@ -298,11 +331,14 @@ __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs
                 f32x4 v0 = *reinterpret_cast<const f32x4*>(&stg[lr * EP_PITCH + c8]);
                 f32x4 v1 = *reinterpret_cast<const f32x4*>(&stg[lr * EP_PITCH + c8 + 4]);
                 if (R) {
-                    const float* rp = R + mb * g.r_bs + mi * g.ldr + n_st;
-                    const f32x4 r0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp));  // read once
-                    const f32x4 r1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp + 4));
-                    v0 += r0;
-                    v1 += r1;
+                    if constexpr (RHOIST) {
+                        v0 += rr0[it];
+                        v1 += rr1[it];
+                    } else {
+                        const float* rp = R + mb * g.r_bs + mi * g.ldr + n_st;
+                        v0 += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp));  // read once
+                        v1 += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp + 4));
+                    }
                 }
                 TO* cp = C + mb * g.c_bs + mi * g.ldc + nc0 + c8;
                 if (ABL & 16) asm volatile("" :: "v"(v0), "v"(v1));   // everything but the store

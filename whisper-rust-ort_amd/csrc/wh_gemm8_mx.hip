@@ -155,6 +155,23 @@ __device__ __forceinline__ void mx_epilogue(const GemmArgs& g, f32x4 (&acc)[TM][
         } else {
             const int mp0 = mw0 + pass * EP_ROWS + r8;
             long mb = mp0 / g.m_per, mi = mp0 % g.m_per;
+            // the pass's residual rows first, all four in flight (k_gemm8's epilogue: one round trip per pass, not per 8-row group)
+            f32x4 rr0[EP_ROWS / 8], rr1[EP_ROWS / 8];
+            if (R) {
+                long qb = mb, qi = mi;
+#pragma unroll
+                for (int it = 0; it < EP_ROWS / 8; it++) {
+                    rr0[it] = f32x4{0, 0, 0, 0};
+                    rr1[it] = f32x4{0, 0, 0, 0};
+                    if (mp0 + it * 8 < g.M && n_st < g.N) {
+                        const float* rp = R + qb * g.r_bs + qi * g.ldr + n_st;
+                        rr0[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp));
+                        rr1[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp + 4));
+                    }
+                    qi += 8;
+                    if (qi >= g.m_per) { qi -= g.m_per; qb += 1; }
+                }
+            }
 #pragma unroll
             for (int it = 0; it < EP_ROWS / 8; it++) {
                 const int lr = it * 8 + r8, m = mp0 + it * 8;
@@ -162,9 +179,8 @@ __device__ __forceinline__ void mx_epilogue(const GemmArgs& g, f32x4 (&acc)[TM][
                     f32x4 v0 = *reinterpret_cast<const f32x4*>(&stg[lr * EP_PITCH + c8]);
                     f32x4 v1 = *reinterpret_cast<const f32x4*>(&stg[lr * EP_PITCH + c8 + 4]);
                     if (R) {
-                        const float* rp = R + mb * g.r_bs + mi * g.ldr + n_st;
-                        v0 += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp));
-                        v1 += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp + 4));
+                        v0 += rr0[it];
+                        v1 += rr1[it];
                     }
                     TC* cp = C + mb * g.c_bs + mi * g.ldc + nc0 + c8;
                     if (n_st + 8 <= g.N) {
