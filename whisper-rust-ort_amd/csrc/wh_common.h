@@ -62,6 +62,7 @@ __device__ __forceinline__ void store4(bf16* p, float a, float b, float c, float
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7): branch-free, one v_exp + one v_rcp, about half the
 // VALU work of libm erff.  The 1e-3 logit budget of the f32 mode is four orders of magnitude above it.
 __device__ __forceinline__ float erf_as(float x) {
+#pragma clang fp contract(off)   // (only the fmaf calls below fuse: the same bits in every kernel that inlines this)
     const float ax = fabsf(x);
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
     float p = fmaf(1.061405429f, t, -1.453152027f);
@@ -71,7 +72,10 @@ __device__ __forceinline__ float erf_as(float x) {
     const float e = 1.0f - p * t * __expf(-ax * ax);
     return copysignf(e, x);
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf(float x) {
+#pragma clang fp contract(off)
+    return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
+}
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -196,6 +200,34 @@ __device__ __forceinline__ void ln_partial_sum(const float* __restrict__ part, i
             s2 += ok ? v[u].y : 0.0f;
         }
     }
+}
+
+// Epilogue arithmetic of kernels that must agree BIT FOR BIT whichever of them computes a row (k_dec_gemm / k_dec_gemm_wide,
+// k_lm_head / k_lm_head_tile: the choice follows the batch, a clip's result must not): explicit, un-contracted operations, so
+// the value does not depend on how the compiler happens to fuse multiplies and adds in each kernel (moving a load in
+// k_dec_gemm_wide once changed an fma choice and with it a token of the fp8 path).
+__device__ __forceinline__ float wh_ln_fold(float acc, float mean, float rstd, float s, float c) {   // rstd (acc - mean s) + c
+#pragma clang fp contract(off)
+    const float p = mean * s;
+    const float t = acc - p;
+    const float u = rstd * t;
+    return u + c;
+}
+// {mean, rstd} of a row from its {sum x, sum x^2}: biased variance, eps 1e-5 (torch LayerNorm)
+__device__ __forceinline__ void wh_ln_mean_rstd(float s1, float s2, float inv_or_k, bool is_inv, float& mean, float& rstd) {
+#pragma clang fp contract(off)
+    mean = is_inv ? s1 * inv_or_k : s1 / inv_or_k;
+    const float ex2 = is_inv ? s2 * inv_or_k : s2 / inv_or_k;
+    const float var = ex2 - mean * mean;
+    rstd = rsqrtf(fmaxf(var, 0.0f) + 1e-5f);
+}
+__device__ __forceinline__ float wh_scale(float acc, float ws) {   // acc * ws (fp8 weights: the channel scale; exact for ws = 1)
+#pragma clang fp contract(off)
+    return acc * ws;
+}
+__device__ __forceinline__ float wh_add(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
 }
 
 #define WH_HIP_CHECK(expr)                                                                      \

@@ -229,8 +229,7 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
             const int r = wave * 16 + fl;
             const float s1 = (lnred[r * 2] + lnred[(ROWS + r) * 2]) + (lnred[(2 * ROWS + r) * 2] + lnred[(3 * ROWS + r) * 2]);
             const float s2 = (lnred[r * 2 + 1] + lnred[(ROWS + r) * 2 + 1]) + (lnred[(2 * ROWS + r) * 2 + 1] + lnred[(3 * ROWS + r) * 2 + 1]);
-            ln_mean = s1 / (float)a.K;
-            ln_rstd = rsqrtf(fmaxf(s2 / (float)a.K - ln_mean * ln_mean, 0.0f) + 1e-5f);  // biased variance, eps 1e-5
+            wh_ln_mean_rstd(s1, s2, (float)a.K, false, ln_mean, ln_rstd);
             const f32x4 sv = *reinterpret_cast<const f32x4*>(a.ln_s + en);
             ln_sv[0] = sv[0]; ln_sv[1] = sv[1]; ln_sv[2] = sv[2]; ln_sv[3] = sv[3];
         }
@@ -318,8 +317,8 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            s[e] *= pre_ws[e];  // fp8 weights: the channel scale (1 otherwise)
-            v[e] = a.ln_part ? ln_rstd * (s[e] - ln_mean * ln_sv[e]) + pre_bias[e] : s[e] + pre_bias[e];
+            s[e] = wh_scale(s[e], pre_ws[e]);  // fp8 weights: the channel scale (1 otherwise)
+            v[e] = a.ln_part ? wh_ln_fold(s[e], ln_mean, ln_rstd, ln_sv[e], pre_bias[e]) : wh_add(s[e], pre_bias[e]);
             if (a.act == 1) v[e] = gelu_erf(v[e]);
             v[e] += pre_r[e];
         }
@@ -339,9 +338,9 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
             }
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const float v = s[e] * pre_ws[e] + pre_bias[e] + pre_r[e];  // producers have no activation
+                const float v = wh_add(wh_add(wh_scale(s[e], pre_ws[e]), pre_bias[e]), pre_r[e]);  // producers have no activation
                 s1 += v;
-                s2 += v * v;
+                s2 = __builtin_fmaf(v, v, s2);   // explicit: the same bits in k_dec_gemm and k_dec_gemm_wide
             }
         }
         s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
@@ -412,6 +411,24 @@ __global__ __launch_bounds__(NW * 64, 2) void k_dec_gemm_wide(SkinnyArgs a) {
             lnred[(q * ROWS + r) * 2 + 1] = s2;
         }
     }
+    // per-column operands of the tiles this wave finishes: requested before the main loop where the register file has room
+    // (two column tiles per workgroup: ~165 of 256 registers), after it otherwise (four column tiles: 253) — there they cost
+    // one more memory round trip per launch
+    constexpr bool EARLY_COLS = NT <= 2;
+    f32x4 pre_bias[TPW], pre_ws[TPW], pre_g[TPW], pre_sv[TPW];
+    auto load_cols = [&]() {
+#pragma unroll
+        for (int j = 0; j < TPW; j++) {
+            pre_bias[j] = f32x4{0, 0, 0, 0}; pre_ws[j] = f32x4{1, 1, 1, 1}; pre_g[j] = f32x4{1, 1, 1, 1}; pre_sv[j] = f32x4{0, 0, 0, 0};
+            if (ep_ok[j]) {
+                if (a.bias) pre_bias[j] = *reinterpret_cast<const f32x4*>(a.bias + en[j]);
+                if (a.wscale) pre_ws[j] = *reinterpret_cast<const f32x4*>(a.wscale + en[j]);
+                if (a.xgamma) pre_g[j] = *reinterpret_cast<const f32x4*>(a.xgamma + en[j]);
+                if (a.ln_part) pre_sv[j] = *reinterpret_cast<const f32x4*>(a.ln_s + en[j]);
+            }
+        }
+    };
+    if constexpr (EARLY_COLS) load_cols();
     f32x4 acc[NT][MT];
 #pragma unroll
     for (int nt = 0; nt < NT; nt++)
@@ -440,17 +457,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_dec_gemm_wide(SkinnyArgs a) {
             }
         }
     }
-    f32x4 pre_bias[TPW], pre_ws[TPW], pre_g[TPW], pre_sv[TPW];
-#pragma unroll
-    for (int j = 0; j < TPW; j++) {
-        pre_bias[j] = f32x4{0, 0, 0, 0}; pre_ws[j] = f32x4{1, 1, 1, 1}; pre_g[j] = f32x4{1, 1, 1, 1}; pre_sv[j] = f32x4{0, 0, 0, 0};
-        if (ep_ok[j]) {
-            if (a.bias) pre_bias[j] = *reinterpret_cast<const f32x4*>(a.bias + en[j]);
-            if (a.wscale) pre_ws[j] = *reinterpret_cast<const f32x4*>(a.wscale + en[j]);
-            if (a.xgamma) pre_g[j] = *reinterpret_cast<const f32x4*>(a.xgamma + en[j]);
-            if (a.ln_part) pre_sv[j] = *reinterpret_cast<const f32x4*>(a.ln_s + en[j]);
-        }
-    }
+    if constexpr (!EARLY_COLS) load_cols();
     f32x4* red = reinterpret_cast<f32x4*>(smem_raw);
 #pragma unroll
     for (int nt = 0; nt < NT; nt++)
@@ -476,13 +483,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_dec_gemm_wide(SkinnyArgs a) {
                 const int r = (t % MT) * 16 + fl;
                 const float s1 = (lnred[r * 2] + lnred[(ROWS + r) * 2]) + (lnred[(2 * ROWS + r) * 2] + lnred[(3 * ROWS + r) * 2]);
                 const float s2 = (lnred[r * 2 + 1] + lnred[(ROWS + r) * 2 + 1]) + (lnred[(2 * ROWS + r) * 2 + 1] + lnred[(3 * ROWS + r) * 2 + 1]);
-                ln_mean = s1 / (float)a.K;
-                ln_rstd = rsqrtf(fmaxf(s2 / (float)a.K - ln_mean * ln_mean, 0.0f) + 1e-5f);
+                wh_ln_mean_rstd(s1, s2, (float)a.K, false, ln_mean, ln_rstd);
             }
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const float sc = s[e] * pre_ws[j][e];  // fp8 weights: the channel scale (1 otherwise)
-                v[e] = a.ln_part ? ln_rstd * (sc - ln_mean * pre_sv[j][e]) + pre_bias[j][e] : sc + pre_bias[j][e];
+                const float sc = wh_scale(s[e], pre_ws[j][e]);  // fp8 weights: the channel scale (1 otherwise)
+                v[e] = a.ln_part ? wh_ln_fold(sc, ln_mean, ln_rstd, pre_sv[j][e], pre_bias[j][e]) : wh_add(sc, pre_bias[j][e]);
                 if (a.act == 1) v[e] = gelu_erf(v[e]);
                 v[e] += pre_r[j][e];
             }
@@ -496,7 +502,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_dec_gemm_wide(SkinnyArgs a) {
             if (ep_ok[j]) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const float u = s[e] * pre_ws[j][e] + pre_bias[j][e] + pre_r[j][e];
+                    const float u = wh_add(wh_add(wh_scale(s[e], pre_ws[j][e]), pre_bias[j][e]), pre_r[j][e]);
                     s1 += u;
                     s2 += u * u;
                 }
@@ -564,9 +570,10 @@ __global__ __launch_bounds__(256) void k_lm_head(SkinnyArgs a) {
         if (tid < ROWS) {
             const float s1 = (lnq[tid * 2] + lnq[(ROWS + tid) * 2]) + (lnq[(2 * ROWS + tid) * 2] + lnq[(3 * ROWS + tid) * 2]);
             const float s2 = (lnq[tid * 2 + 1] + lnq[(ROWS + tid) * 2 + 1]) + (lnq[(2 * ROWS + tid) * 2 + 1] + lnq[(3 * ROWS + tid) * 2 + 1]);
-            const float mean = s1 / (float)a.K;
+            float mean, rstd;
+            wh_ln_mean_rstd(s1, s2, (float)a.K, false, mean, rstd);
             lnstat[2 * tid] = mean;
-            lnstat[2 * tid + 1] = rsqrtf(fmaxf(s2 / (float)a.K - mean * mean, 0.0f) + 1e-5f);
+            lnstat[2 * tid + 1] = rstd;
         }
     }
     const int pos = *a.pos_p;
@@ -631,7 +638,7 @@ __global__ __launch_bounds__(256) void k_lm_head(SkinnyArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int nn = n + e;
-                const float v = a.ln_part ? rstd * (acc[t][e] - mean * sv[e]) + cv[e] : acc[t][e];
+                const float v = a.ln_part ? wh_ln_fold(acc[t][e], mean, rstd, sv[e], cv[e]) : acc[t][e];
                 if (nn < a.N && m < a.M) {
                     if (a.logits && gen >= 0 && gen < a.logits_rows)
                         a.logits[((long)m * a.logits_rows + gen) * a.N + nn] = v;

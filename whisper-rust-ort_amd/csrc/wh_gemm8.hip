@@ -474,9 +474,10 @@ __global__ __launch_bounds__(512, 2) void k_lm_head_tile(SkinnyArgs a) {
     if (a.ln_part && tid < BM) {
         const float s1 = (lnq[tid * 2] + lnq[(BM + tid) * 2]) + (lnq[(2 * BM + tid) * 2] + lnq[(3 * BM + tid) * 2]);
         const float s2 = (lnq[tid * 2 + 1] + lnq[(BM + tid) * 2 + 1]) + (lnq[(2 * BM + tid) * 2 + 1] + lnq[(3 * BM + tid) * 2 + 1]);
-        const float mean = s1 / (float)a.K;
+        float mean, rstd;
+        wh_ln_mean_rstd(s1, s2, (float)a.K, false, mean, rstd);
         lnstat[2 * tid] = mean;
-        lnstat[2 * tid + 1] = rsqrtf(fmaxf(s2 / (float)a.K - mean * mean, 0.0f) + 1e-5f);
+        lnstat[2 * tid + 1] = rstd;
     }
     read_frags(0, 0);
     for (int kt = 0; kt < nk; kt += 2) {
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void k_lm_head_tile(SkinnyArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int nn = n + e;
-                const float v = a.ln_part ? rstd * (acc[i][j][e] - mean * sv[j][e]) + cv[j][e] : acc[i][j][e];
+                const float v = a.ln_part ? wh_ln_fold(acc[i][j][e], mean, rstd, sv[j][e], cv[j][e]) : acc[i][j][e];
                 if (nn < a.N && m < a.M) {
                     if (a.logits && gen >= 0 && gen < a.logits_rows) a.logits[((long)m * a.logits_rows + gen) * a.N + nn] = v;
                     const bool sup = (mbits[j] >> e) & 1u;
@@ -591,8 +592,9 @@ __global__ __launch_bounds__(256) void k_ln_stats(const float* __restrict__ part
         for (int u = 0; u < 8; u++)
             if (g0 + u < groups) { s1 += v[u].x; s2 += v[u].y; }
     }
-    const float mean = s1 * inv_d;
-    *reinterpret_cast<f32x2*>(stat + 2 * r) = f32x2{mean, rsqrtf(fmaxf(s2 * inv_d - mean * mean, 0.0f) + 1e-5f)};   // biased variance, eps 1e-5
+    float mean, rstd;
+    wh_ln_mean_rstd(s1, s2, inv_d, true, mean, rstd);
+    *reinterpret_cast<f32x2*>(stat + 2 * r) = f32x2{mean, rstd};
 }
 
 // LM head at hundreds of rows (bf16 operands): argmax partials per row = column tiles x 4 (layout [part][x_mpad])

@@ -92,6 +92,18 @@ __device__ __forceinline__ void mx_epilogue(const GemmArgs& g, f32x4 (&acc)[TM][
             if (g.wscale) pw[j] = *reinterpret_cast<const f32x4*>(g.wscale + n);
         }
     }
+    // per-row bias / channel scale (the per-clip V^T product) of all of this lane's rows, requested together
+    float rowb[TM], roww[TM];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int m = min(mw0 + i * 16 + fl, g.M - 1);
+        rowb[i] = 0.0f;
+        roww[i] = 1.0f;
+        if (g.bias_mode == 2) {
+            if (g.bias) rowb[i] = g.bias[m];
+            if (g.wscale) roww[i] = g.wscale[m];
+        }
+    }
     const int c8 = (lane & 7) * 8, r8 = lane >> 3;
     const int n_st = nw0 + c8;
 #pragma unroll
@@ -99,12 +111,7 @@ __device__ __forceinline__ void mx_epilogue(const GemmArgs& g, f32x4 (&acc)[TM][
 #pragma unroll
         for (int ii = 0; ii < 2; ii++) {
             const int i = pass * 2 + ii;
-            const int m = mw0 + i * 16 + fl;
-            float bm = 0.0f, wmul = 1.0f;
-            if (g.bias_mode == 2 && m < g.M) {
-                if (g.bias) bm = g.bias[m];
-                if (g.wscale) wmul = g.wscale[m];
-            }
+            const float bm = rowb[i], wmul = roww[i];
 #pragma unroll
             for (int j = 0; j < TN; j++) {
                 float v[4];
