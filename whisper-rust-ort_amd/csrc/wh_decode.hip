@@ -504,7 +504,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_dec_gemm_wide(SkinnyArgs a) {
                 for (int e = 0; e < 4; e++) {
                     const float u = wh_add(wh_add(wh_scale(s[e], pre_ws[j][e]), pre_bias[j][e]), pre_r[j][e]);
                     s1 += u;
-                    s2 += u * u;
+                    s2 = __builtin_fmaf(u, u, s2);
                 }
             }
             s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
