@@ -411,10 +411,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_dec_gemm_wide(SkinnyArgs a) {
             lnred[(q * ROWS + r) * 2 + 1] = s2;
         }
     }
-    // per-column operands of the tiles this wave finishes: requested before the main loop where the register file has room
-    // (two column tiles per workgroup: ~165 of 256 registers), after it otherwise (four column tiles: 253) — there they cost
-    // one more memory round trip per launch
-    constexpr bool EARLY_COLS = NT <= 2;
+    // per-column operands of the tiles this wave finishes: requested AFTER the main loop.  Requesting them before it where the
+    // register file has room (two column tiles per workgroup) was measured slower in round 3 — the trace of the whole step reads
+    // 9.68 instead of 8.74 us for the QKV / cross-Q launches, 7.17 instead of 6.97 us for the out-projections
+    // (profiles/r03_kernel_stats_base_bf16_b1024.txt history) — they only lengthen the queue in front of the first fragments.
+    constexpr bool EARLY_COLS = false;
     f32x4 pre_bias[TPW], pre_ws[TPW], pre_g[TPW], pre_sv[TPW];
     auto load_cols = [&]() {
 #pragma unroll
