@@ -85,3 +85,42 @@ def test_product_package_never_imports_the_oracle():
             if fn.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dp, fn), errors="ignore").read()
                 assert "libwhisper_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, fn
+
+
+def test_cu_mask_helper_and_ctx_opts_validation():
+    """wh_ctx_create_ex validates its options before it touches HIP (so this runs without a GPU): struct size, NULL masks, empty masks,
+    masks that leave an XCD unrestricted (bit i = compute unit i / 8 of XCD i % 8: an XCD without a bit is not restricted at all)."""
+    w = wb.cu_mask(0, 64)
+    assert w.dtype == np.uint32 and w.size == 8 and int(w[0]) == 0xFFFFFFFF and int(w[1]) == 0xFFFFFFFF and not w[2:].any()
+    assert sum(bin(int(x)).count("1") for x in wb.cu_mask(64, 192)) == 192
+    with pytest.raises(ValueError):
+        wb.cu_mask(200, 100)
+    lib = wb.load_library()
+    fake_model = C.create_string_buffer(1 << 16)          # never dereferenced: every case below fails validation first
+    u32p = C.POINTER(C.c_uint32)
+
+    def create(struct_size, max_batch, enc, dec, enc_words=None, dec_words=None):
+        e = np.ascontiguousarray(enc, np.uint32) if enc is not None else None
+        d = np.ascontiguousarray(dec, np.uint32) if dec is not None else None
+        o = wb.WhCtxOpts(struct_size, max_batch, 0,
+                         e.ctypes.data_as(u32p) if e is not None else None, (e.size if e is not None else 0) if enc_words is None else enc_words,
+                         d.ctypes.data_as(u32p) if d is not None else None, (d.size if d is not None else 0) if dec_words is None else dec_words)
+        h = C.c_void_p()
+        rc = lib.wh_ctx_create_ex(C.cast(fake_model, C.c_void_p), C.byref(o), C.byref(h))
+        return rc, (lib.wh_last_error(None) or b"").decode()
+
+    ok_size = C.sizeof(wb.WhCtxOpts)
+    rc, msg = create(ok_size - 8, 4, None, None)
+    assert rc == 4 and "struct_size" in msg
+    rc, msg = create(ok_size, 0, None, None)
+    assert rc == 4 and "max_batch" in msg
+    rc, msg = create(ok_size, 4, None, None, enc_words=8)
+    assert rc == 4 and "NULL CU mask" in msg
+    rc, msg = create(ok_size, 4, np.zeros(8, np.uint32), None)
+    assert rc == 4 and "no bit set" in msg
+    one_xcd = np.zeros(8, np.uint32)
+    one_xcd[0] = 0x01010101                                # compute units 0..3 of XCD 0 only
+    rc, msg = create(ok_size, 4, one_xcd, None)
+    assert rc == 4 and "every XCD" in msg
+    rc, msg = create(ok_size, 4, wb.cu_mask(0, 64), wb.cu_mask(3, 5))   # bits 3..7: XCDs 0..2 uncovered
+    assert rc == 4 and "every XCD" in msg

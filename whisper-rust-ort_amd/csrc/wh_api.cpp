@@ -733,15 +733,15 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     // A mask must restrict every XCD it is meant to restrict: bit i is compute unit i / 8 of XCD i % 8, and an XCD none of
     // whose bits is set is not restricted at all (measured, tools/cu_mask_probe.hip) — refuse such a mask instead of silently
     // running on compute units the caller meant to leave to the other stream.  A mask naming every compute unit is no mask.
-    WH_HIP_CHECK(hipSetDevice(m->device));
-    int n_cus = 0;
-    WH_HIP_CHECK(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, m->device));
     auto xcds_covered = [](const uint32_t* w, size_t n) { unsigned seen = 0; for (size_t i = 0; i < n * 32; i++) if (w[i >> 5] >> (i & 31) & 1) seen |= 1u << (i & 7); return seen == 0xFFu; };
     if ((opts->enc_cu_mask_words && !xcds_covered(opts->enc_cu_mask, opts->enc_cu_mask_words)) ||
         (opts->dec_cu_mask_words && !xcds_covered(opts->dec_cu_mask, opts->dec_cu_mask_words))) {
         wh_set_error("wh_ctx_create_ex: a CU mask must select at least one compute unit of every XCD (bit i = compute unit i / 8 of XCD i %% 8)");
         return WH_ERR_ARG;
     }
+    WH_HIP_CHECK(hipSetDevice(m->device));
+    int n_cus = 0;
+    WH_HIP_CHECK(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, m->device));
     const bool enc_masked = opts->enc_cu_mask_words && (int)mask_bits(opts->enc_cu_mask, opts->enc_cu_mask_words) < n_cus;
     const bool dec_masked = opts->dec_cu_mask_words && (int)mask_bits(opts->dec_cu_mask, opts->dec_cu_mask_words) < n_cus;
     auto* c = new wh_ctx();
