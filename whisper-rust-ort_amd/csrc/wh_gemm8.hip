@@ -381,7 +381,7 @@ __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs
 // (k_gemm8's BN = 256 geometry and LDS-DMA ring; the activation rows come from the decode slab layout [K/32][mpad][32], which
 // is an LDS tile per k-step as it stands), so the embedding passes L2 once per 256 rows; the epilogue never stores the tile —
 // it folds the final LayerNorm (rstd (acc - mean s[n]) + c[n]), applies the suppress mask and keeps one (max, index) per row and
-// wave: one partial per (column tile, wave column) and row.
+// wave, merged over the four waves of a row through LDS: one partial per (column tile, row).
 // Bit-identical logits: the same MFMA chain over k as k_lm_head (weights as the row operand, k ascending, one accumulator),
 // LayerNorm partial sums reduced in the same order, the same epilogue expression — so the launcher may pick by the call's
 // row count (tests/test_hip_parity.py::test_wide_batch_decode_gemm_is_bit_identical runs both).
@@ -517,7 +517,8 @@ __global__ __launch_bounds__(512, 2) void k_lm_head_tile(SkinnyArgs a) {
         mbits[j] = 0;
         if (n < a.N) mbits[j] = mask[n >> 5] >> (n & 31);   // suppress bits of this lane's 4 columns
     }
-    const int part = ct * G::WN + wn;
+    float* red_v = reinterpret_cast<float*>(smem);            // [4][256] — every wave is past the last barrier of the main loop
+    int* red_i = reinterpret_cast<int*>(smem) + G::WN * BM;
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const int rloc = wm * (TM * 16) + i * 16 + fl, m = m0 + rloc;
@@ -553,12 +554,29 @@ __global__ __launch_bounds__(512, 2) void k_lm_head_tile(SkinnyArgs a) {
         take1 = v1 > v0 || (v1 == v0 && i1 < i0);
         bv = take1 ? v1 : v0;
         bi = take1 ? i1 : i0;
-        if (fg == 0 && m < a.M) {
-            a.part_val[(long)part * a.x_mpad + m] = bv;
-            a.part_idx[(long)part * a.x_mpad + m] = bi;
+        if (fg == 0) {   // this wave's (max, index) of row rloc: the four waves that share the row meet in LDS (the ring is idle now)
+            red_v[wn * BM + rloc] = bv;
+            red_i[wn * BM + rloc] = bi;
         }
     }
+    __syncthreads();
+    // one partial per (column tile, row): 203 instead of 812 partials per row for k_argmax_finish to read (strided by the row pitch)
+    if (tid < BM && m0 + tid < a.M) {
+        float bv = red_v[tid];
+        int bi = red_i[tid];
+#pragma unroll
+        for (int w = 1; w < G::WN; w++) {
+            const float v1 = red_v[w * BM + tid];
+            const int i1 = red_i[w * BM + tid];
+            const bool take1 = v1 > bv || (v1 == bv && i1 < bi);
+            bv = take1 ? v1 : bv;
+            bi = take1 ? i1 : bi;
+        }
+        a.part_val[(long)ct * a.x_mpad + m0 + tid] = bv;
+        a.part_idx[(long)ct * a.x_mpad + m0 + tid] = bi;
+    }
 }
+
 
 template <typename TO, int BN, int LN = 0>
 void launch8(hipStream_t s, const GemmArgs& g) {
@@ -603,7 +621,7 @@ bool wh_lm_head_tile_applicable(const SkinnyArgs& a) {
     const int min_rows = e ? atoi(e) : 256;
     return min_rows > 0 && a.M >= min_rows && (a.K % BK) == 0 && a.K / BK >= 4 && a.X != nullptr && a.xpart == nullptr && a.wscale == nullptr;
 }
-int wh_lm_head_tile_parts(const SkinnyArgs& a) { return ((a.N + 255) / 256) * Geo<256>::WN; }
+int wh_lm_head_tile_parts(const SkinnyArgs& a) { return (a.N + 255) / 256; }
 void wh_launch_lm_head_tile(hipStream_t s, const SkinnyArgs& a) {
     typedef Geo<256> G;
     const size_t sm = (size_t)G::NSLOT * G::SLOT + (size_t)BM * 2 * 4 * 5;   // ring + LayerNorm statistics ([256][2] + four quarter sums)
