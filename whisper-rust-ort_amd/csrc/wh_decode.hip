@@ -1382,6 +1382,8 @@ void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void
 #define WH_CA1(T_, N_, U_, NT_) do { set_max_smem(k_dec_cross_attn<T_, N_, U_, NT_>, sm);                                                 \
                                      hipLaunchKernelGGL((k_dec_cross_attn<T_, N_, U_, NT_>), grid, dim3(256), sm, s, (const T_*)q, (const T_*)ck, \
                                              (const T_*)cv, part, ml, S, d, n_heads, splits, (T_*)(splits == 1 ? out : nullptr), mpad); } while (0)
+    static const int nt_env = [] { const char* e = getenv("WH_CROSS_NT"); return e ? atoi(e) : -1; }();   // (A/B runs: force the non-temporal K/V loads off / on)
+    if (nt_env >= 0) stream_nt = nt_env != 0;
 #define WH_CA(T_, N_, U_) do { if (stream_nt) WH_CA1(T_, N_, U_, true); else WH_CA1(T_, N_, U_, false); } while (0)
     if (prec == WH_PREC_F32) {
         const int nch = (d / 4 + 63) / 64;  // f32: 4 elements per chunk
@@ -1391,7 +1393,12 @@ void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void
     } else {
         const int nch = (d / 8 + 63) / 64;
         static const int unroll_env = [] { const char* e = getenv("WH_CROSS_UNROLL"); return e ? atoi(e) : 0; }();   // (A/B runs)
-        if (nch == 1) { if ((unroll_env ? unroll_env : wh_dbg_cross_unroll) == 8) WH_CA(bf16, 1, 8); else WH_CA(bf16, 1, 4); }
+        if (nch == 1) {
+            const int un = unroll_env ? unroll_env : wh_dbg_cross_unroll;
+            if (un == 8) WH_CA(bf16, 1, 8);
+            else if (un == 2) WH_CA(bf16, 1, 2);
+            else WH_CA(bf16, 1, 4);
+        }
         else if (d % 256 == 0 && getenv("WH_CROSS_ALLHEADS") == nullptr) {   // wide models: one workgroup per 256-column group
             dim3 g3(splits, B, d / 256);
             bf16* o = (bf16*)(splits == 1 ? out : nullptr);
