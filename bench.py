@@ -46,7 +46,7 @@ MFMA_F32_PEAK_TF = 157.3
 Hip = wb.HipRuntime   # device-resident PCM (hipMalloc / hipMemcpy of the runtime the library already loaded)
 
 
-def algorithmic_work(dims, n_clips: int, n_prompt: int, max_new: int, kv_esz: int) -> dict:
+def algorithmic_work(dims, n_clips: int, n_prompt: int, max_new: int, kv_esz: int, cross_es: bool = False) -> dict:
     """SURVEY.md §8d formulas, per launch / per batch."""
     d, F, T, Ld, Le, V, M = dims.d_model, dims.ffn, dims.n_audio_ctx, dims.dec_layers, dims.enc_layers, dims.vocab, dims.n_mels
     enc_flop = 2 * d * M * 3 * 3000 + 2 * d * d * 3 * T + Le * (2 * 4 * T * d * d + 2 * 2 * T * T * d + 2 * 2 * T * d * F)
@@ -58,8 +58,9 @@ def algorithmic_work(dims, n_clips: int, n_prompt: int, max_new: int, kv_esz: in
         "enc_flop_per_clip": enc_flop,
         "cross_kv_flop_per_clip": cross_kv_flop,
         "dec_flop_per_clip": dec_flop,
-        # one cross-attention launch reads K and V of one layer for every clip of the batch, once
-        "cross_attn_bytes_per_launch": 2 * T * d * kv_esz * n_clips,   # kv_esz: 4 f32, 2 bf16, 1 e4m3
+        # one cross-attention launch reads K and V of one layer for every clip of the batch, once — or, on the encoder
+        # states (wh_cross_es.hip), the T x d states themselves: the kernel's own algorithmic bytes, half of the K + V form
+        "cross_attn_bytes_per_launch": (1 if cross_es else 2) * T * d * kv_esz * n_clips,   # kv_esz: 4 f32, 2 bf16, 1 e4m3
         "cross_attn_launches": positions * Ld,
         "mel_bytes_per_clip": 480000 * 4 + M * 3000 * 4,
     }
@@ -178,6 +179,9 @@ def main() -> None:
                     help="compute units of the encoder stream in pipeline mode (multiple of 8: the same count from every XCD); "
                          "0 = no CU masks, two plain streams; default: the measured best (profiles/r03_cu_partition_sweep.txt)")
     ap.add_argument("--dec-cus", type=int, default=-1, help="compute units of the token-loop stream (default: the other 256 - enc-cus)")
+    ap.add_argument("--cross-es", default="auto", choices=["auto", "on", "off"],
+                    help="token-loop cross-attention on the encoder states (wh_cross_es.hip) instead of the projected K / V cache; "
+                         "auto = the library's rule (bf16 whisper-base geometry, contexts of >= 256 clips)")
     ap.add_argument("--preset", default="base")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "fp8"])
     ap.add_argument("--max-new-tokens", type=int, default=128)
@@ -279,13 +283,14 @@ def main() -> None:
     model = wb.Model(f"synthetic:{a.preset}:{a.seed}", dev, prec)
     assert a.clips % a.streams == 0, "--clips must be a multiple of --streams"
     per_stream = a.clips // a.streams
+    ces = {"auto": None, "on": True, "off": False}[a.cross_es]
     if a.pipeline:
         # encoder stream on the low mask bits, token loop on the bits above them (disjoint unless --dec-cus says otherwise)
         em = wb.cu_mask(0, a.enc_cus) if a.enc_cus else None
         dm = wb.cu_mask(wb.N_CUS - a.dec_cus, a.dec_cus) if a.dec_cus else None
-        ctxs = [wb.Context(model, per_stream, enc_cu_mask=em, dec_cu_mask=dm, two_streams=True)]
+        ctxs = [wb.Context(model, per_stream, enc_cu_mask=em, dec_cu_mask=dm, two_streams=True, cross_es=ces)]
     else:
-        ctxs = [wb.Context(model, per_stream) for _ in range(a.streams)]
+        ctxs = [wb.Context(model, per_stream, cross_es=ces) for _ in range(a.streams)]
     ctx = ctxs[0]
     hip = Hip()
 
@@ -453,7 +458,8 @@ def main() -> None:
         n_results = len(toks)
 
     if rank == 0:
-        work = algorithmic_work(dims, per_stream, len(prompt), a.max_new_tokens, 1 if prec == wb.WH_PREC_FP8 else esz)
+        cross_es = ctxs[0].cross_mode == 1
+        work = algorithmic_work(dims, per_stream, len(prompt), a.max_new_tokens, 1 if prec == wb.WH_PREC_FP8 else esz, cross_es)
         audio_s = 30.0 * a.clips * a.steps * world
         ms_per_step = elapsed / a.steps * 1e3
         # Roofline of the dominant kernel (k_dec_cross_attn: largest single-kernel share in every
@@ -468,7 +474,7 @@ def main() -> None:
         traffic = None
         traffic_stamp = None
         # the dominant kernel's variants: e4m3 cache (fp8 mode), one workgroup per 256-column group (wide models), all heads per workgroup
-        dom_kernel = ("k_dec_cross_attn8" if prec == wb.WH_PREC_FP8 else
+        dom_kernel = ("k_dec_cross_attn_es" if cross_es else "k_dec_cross_attn8" if prec == wb.WH_PREC_FP8 else
                       "k_dec_cross_attn_cg" if (prec == wb.WH_PREC_BF16 and dims.d_model > 512 and dims.d_model % 256 == 0) else "k_dec_cross_attn")
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):   # HBM bytes per launch from rocprofv3 --pmc passes (see profiles/README.md)
@@ -482,6 +488,8 @@ def main() -> None:
                     "traffic_collected_at": traffic_stamp,
                     "kernel": dom_kernel, "avg_launch_us": avg_s * 1e6,
                     "launches_timed": live["launches"], "alg_bytes_per_launch": work["cross_attn_bytes_per_launch"],
+                    "streams": ("the encoder states [clips][1500][d] once per launch (cross-attention on the encoder states; the projected K + V "
+                                "form of the same attention reads twice these bytes)" if cross_es else "K and V of one decoder layer for every clip of the launch"),
                     "share_of_kernel_time": breakdown["dec_cross_attn"]["ms"] / tot_ms}
         d_, F_, T_, Le_ = dims.d_model, dims.ffn, dims.n_audio_ctx, dims.enc_layers
         attn_flop = Le_ * 2 * 2 * T_ * T_ * d_ * a.clips

@@ -131,6 +131,11 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out);
  * A CU mask is `words` 32-bit words; on MI355X bit i selects compute unit i / 8 of XCD i % 8 (256 bits), so the low n
  * bits are n compute units spread evenly over the 8 XCDs.  words == 0: the stream may use the whole chip. */
 #define WH_CTX_TWO_STREAMS 1 /* separate encoder / decode streams even without CU masks */
+/* Cross-attention of the token loop computed on the encoder states themselves instead of the per-layer projected K / V
+ * (bf16 models of whisper-base geometry; algebraically the same attention, half the bytes streamed per token and no
+ * cross-K/V cache).  Default: on for contexts of max_batch >= 256.  _ON on a model without the geometry is refused. */
+#define WH_CTX_CROSS_ES_ON 2
+#define WH_CTX_CROSS_ES_OFF 4
 typedef struct {
     size_t struct_size;          /* sizeof(wh_ctx_opts): guards against a caller built for another layout */
     int max_batch;               /* as wh_ctx_create */
@@ -142,6 +147,9 @@ typedef struct {
 } wh_ctx_opts;
 int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out);
 void wh_ctx_free(wh_ctx* c);
+/* what the token loop's cross-attention streams: 0 = the projected K / V of every decoder layer (2 Ld S d elements per clip and
+ * token, the reference's present.{i}.encoder.{key,value}, src/main.rs:771-787), 1 = the encoder states (Ld S d), -1 = c is NULL */
+int wh_ctx_cross_mode(const wh_ctx* c);
 const char* wh_last_error(const wh_ctx* c); /* c == NULL: last load/create error of this thread */
 int wh_get_timings(const wh_ctx* c, wh_timing* out);
 

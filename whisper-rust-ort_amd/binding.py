@@ -30,7 +30,7 @@ STATUS = {0: "WH_OK", 1: "WH_ERR_EMPTY_AUDIO", 2: "WH_ERR_BAD_SHAPE", 3: "WH_ERR
 
 # every symbol include/whisper_hip.h declares
 EXPORTS = ("wh_model_load", "wh_model_create", "wh_model_free", "wh_model_get_dims", "wh_model_precision",
-           "wh_model_export_tensor", "wh_ctx_create", "wh_ctx_create_ex", "wh_ctx_free", "wh_last_error", "wh_get_timings",
+           "wh_model_export_tensor", "wh_ctx_create", "wh_ctx_create_ex", "wh_ctx_free", "wh_ctx_cross_mode", "wh_last_error", "wh_get_timings",
            "wh_mel_frames", "wh_log_mel", "wh_encode", "wh_decode_greedy", "wh_decode_greedy_batch", "wh_transcribe_batch",
            "wh_transcribe_batch_device", "wh_transcribe_batch_device_next", "wh_longform_plan", "wh_transcribe_longform", "wh_profile_enable",
            "wh_profile_get", "wh_synthetic_weights", "wh_e4m3_quantize", "wh_e4m3_dequantize", "wh_abi_version",
@@ -70,6 +70,8 @@ class WhCtxOpts(C.Structure):
 
 
 WH_CTX_TWO_STREAMS = 1
+WH_CTX_CROSS_ES_ON = 2
+WH_CTX_CROSS_ES_OFF = 4
 N_CUS = 256   # MI355X: 8 XCDs x 32 compute units
 
 
@@ -108,6 +110,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.wh_ctx_create_ex.argtypes = [vp, C.POINTER(WhCtxOpts), C.POINTER(vp)]
     L.wh_ctx_free.argtypes = [vp]
     L.wh_ctx_free.restype = None
+    L.wh_ctx_cross_mode.argtypes = [vp]
     L.wh_last_error.argtypes = [vp]
     L.wh_last_error.restype = C.c_char_p
     L.wh_get_timings.argtypes = [vp, C.POINTER(WhTiming)]
@@ -220,18 +223,21 @@ class Context:
     """One stream's workspace + KV cache (reference: per-thread IoBinding + `past`, src/main.rs:786-791)."""
 
     def __init__(self, model: Model, max_batch: int = 1, enc_cu_mask: Optional[np.ndarray] = None,
-                 dec_cu_mask: Optional[np.ndarray] = None, two_streams: bool = False):
+                 dec_cu_mask: Optional[np.ndarray] = None, two_streams: bool = False, cross_es: Optional[bool] = None):
         """enc_cu_mask / dec_cu_mask (uint32 words, see cu_mask()) or two_streams: the chip-partition form of the context
-        (wh_ctx_create_ex) — log-mel + encoder on their own stream, beside the token loop of the previous batch."""
+        (wh_ctx_create_ex) — log-mel + encoder on their own stream, beside the token loop of the previous batch.
+        cross_es: force the token loop's cross-attention onto the encoder states (True) or onto the projected K / V (False);
+        None = the library's rule (bf16 whisper-base geometry, max_batch >= 256)."""
         self.model, self.lib, self.max_batch = model, model.lib, max_batch
         h = C.c_void_p()
-        if enc_cu_mask is None and dec_cu_mask is None and not two_streams:
+        flags = (WH_CTX_TWO_STREAMS if two_streams else 0) | (0 if cross_es is None else (WH_CTX_CROSS_ES_ON if cross_es else WH_CTX_CROSS_ES_OFF))
+        if enc_cu_mask is None and dec_cu_mask is None and not flags:
             rc = self.lib.wh_ctx_create(model.h, max_batch, C.byref(h))
         else:
             em = np.ascontiguousarray(enc_cu_mask, np.uint32) if enc_cu_mask is not None else None
             dm = np.ascontiguousarray(dec_cu_mask, np.uint32) if dec_cu_mask is not None else None
             u32p = C.POINTER(C.c_uint32)
-            o = WhCtxOpts(C.sizeof(WhCtxOpts), max_batch, WH_CTX_TWO_STREAMS if two_streams else 0,
+            o = WhCtxOpts(C.sizeof(WhCtxOpts), max_batch, flags,
                           em.ctypes.data_as(u32p) if em is not None else None, em.size if em is not None else 0,
                           dm.ctypes.data_as(u32p) if dm is not None else None, dm.size if dm is not None else 0)
             rc = self.lib.wh_ctx_create_ex(model.h, C.byref(o), C.byref(h))
@@ -242,6 +248,11 @@ class Context:
     def _check(self, rc: int):
         if rc:
             raise WhisperHipError(rc, (self.lib.wh_last_error(self.h) or b"").decode())
+
+    @property
+    def cross_mode(self) -> int:
+        """0: the token loop streams the projected cross K / V of every layer; 1: the encoder states (wh_cross_es.hip)."""
+        return int(self.lib.wh_ctx_cross_mode(self.h))
 
     # --- the reference's three functions -----------------------------------------------------
     def whisper_log_mel(self, audio_16k: np.ndarray) -> np.ndarray:

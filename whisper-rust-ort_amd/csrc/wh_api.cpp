@@ -328,11 +328,16 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     const bool f8 = prec == WH_PREC_FP8;
     // the cross K/V of all layers are re-read at every position: below ~half the 256 MiB Infinity Cache they are served
     // from it; above, their stream only evicts the decode weights and activations — then they are loaded non-temporally
-    const bool kv_nt = (double)D.dec_layers * 2.0 * nb * S * d * (f8 ? 1 : (double)esz) > 128.0 * 1024 * 1024;
+    const bool kv_nt = (c->cross_es ? 1.0 : (double)D.dec_layers * 2.0) * nb * S * d * (f8 ? 1 : (double)esz) > 128.0 * 1024 * 1024;
     // cross-attention K/V of every decoder layer, once per clip: present.{i}.encoder.{key,value}
     // of the step-0 decoder run (src/main.rs:771-787)
     const long kv_stride = (long)nb * S * d;  // elements between consecutive [nb][S][d] planes
-    {
+    if (c->cross_es) {
+        // no projection: the token loop attends over the encoder states themselves (wh_cross_es.hip).  Their final LayerNorm runs
+        // here, on the decode stream, into decode-side storage — the encoder-side workspace is free for the next pass afterwards
+        Prof pr(c, WH_KG_DEC_GEMM);
+        wh_launch_layernorm(s, prec, c->x, m->enc_ln_w, m->enc_ln_b, c->es_E, (long)nb * S, (int)d);
+    } else {
         Prof pr(c, WH_KG_DEC_GEMM);
         GemmArgs g;
         g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
@@ -405,6 +410,27 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 if (f8) a.xgamma = L.ln2_w;
                 wh_launch_dec_gemm(s, prec, true, a);
             }
+            if (c->cross_es) {
+                const long Hd = (long)D.n_heads * d;
+                {   // LN2 ∘ expanded cross-attention queries qe = blockdiag(Wk_h^T) (Wq LN2(x) + bq): [nb][H d] f32
+                    Prof pr(c, WH_KG_DEC_GEMM);
+                    a = SkinnyArgs();
+                    a.X = c->dxs; a.x_mpad = mpad; a.W = L.cqe_w; a.bias = L.cqe_b; a.C = c->dqe; a.ldc = Hd; a.M = nb; a.N = (int)Hd; a.K = (int)d;
+                    a.ln_part = c->lnpart; a.ln_tiles = ln_tiles_d; a.ln_s = L.cqe_s;
+                    wh_launch_dec_gemm(s, prec, true, a);
+                }
+                {
+                    Prof pr(c, WH_KG_DEC_CROSS_ATTN);
+                    wh_launch_dec_cross_attn_es(s, c->dqe, c->es_E, c->dctx, (int)S, nb, mpad, kv_nt);
+                }
+                {   // Wo blockdiag(Wv_h) ctx + (bo + Wo bv) + residual → x, raw slab, LN3 partials
+                    Prof pr(c, WH_KG_DEC_GEMM);
+                    a = SkinnyArgs();
+                    a.X = c->dctx; a.x_mpad = mpad; a.W = L.coe_w; a.bias = L.coe_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
+                    a.M = nb; a.N = (int)d; a.K = (int)Hd; a.xslab_out = c->dxs; a.stats_out = c->lnpart;
+                    wh_launch_dec_gemm(s, prec, true, a);
+                }
+            } else {
             {   // LN2 ∘ cross-attention query
                 Prof pr(c, WH_KG_DEC_GEMM);
                 a = SkinnyArgs();
@@ -432,6 +458,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 a.M = nb; a.N = (int)d; a.K = (int)d; a.xslab_out = c->dxs; a.stats_out = c->lnpart;
                 if (f8) a.xgamma = L.ln3_w;
                 wh_launch_dec_gemm(s, prec, true, a);
+            }
             }
             {   // LN3 ∘ fc1 + GELU (slab output)
                 Prof pr(c, WH_KG_DEC_GEMM);
@@ -769,7 +796,19 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     const size_t o_x = cv.take(B * S * d * 4), o_xn = cv.take(B * S * d * esz), o_qk = cv.take(B * S * 2 * d * esz);
     const size_t o_vT = cv.take(B * d * c->ldv * esz), o_att = cv.take(B * S * d * esz), o_h = cv.take(B * S * F * esz);
     const size_t o_enc = cv.take(B * S * d * esz), o_encf = cv.take(B * S * d * 4);
-    const size_t o_ckv = cv.take(Ld * 2 * B * S * d * esz);
+    // Cross-attention on the encoder states (bf16, whisper-base geometry, contexts of at least one workgroup per CU): the token
+    // loop streams the S x d states themselves instead of the projected K and V of every layer — no cross-K/V cache.  Decided
+    // from the model and the context only (WH_CTX_CROSS_ES_ON / _OFF or WH_CROSS_ES=1 / 0 override the size rule).
+    c->cross_es = m->cross_es && max_batch >= 256;
+    if (opts->flags & WH_CTX_CROSS_ES_ON) c->cross_es = m->cross_es;
+    if (opts->flags & WH_CTX_CROSS_ES_OFF) c->cross_es = false;
+    if (const char* e = getenv("WH_CROSS_ES")) c->cross_es = m->cross_es && atoi(e) != 0;
+    if ((opts->flags & WH_CTX_CROSS_ES_ON) && !m->cross_es) {
+        delete c;
+        wh_set_error("wh_ctx_create_ex: WH_CTX_CROSS_ES_ON needs a bf16 model of whisper-base geometry (d_model 512, 8 heads)");
+        return WH_ERR_UNSUPPORTED;
+    }
+    const size_t o_ckv = cv.take(c->cross_es ? B * S * d * esz : Ld * 2 * B * S * d * esz);
     const bool f8 = m->prec == WH_PREC_FP8;
     const size_t o_ckv8 = f8 ? cv.take(Ld * 2 * B * S * d) : 0, o_kvam = f8 ? cv.take(Ld * 2 * B * H * 4) : 0;
     // fp8-MFMA encoder (wh_gemm8_mx.hip): MX activations when every contraction length is one the kernel takes
@@ -790,6 +829,7 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     const size_t o_dx = cv.take(B * d * 4), o_dxn = cv.take(MP * d * esz), o_dqkv = cv.take(B * 3 * d * esz);
     const size_t o_dxs = cv.take(MP * d * esz), o_lnp = cv.take((d / 16) * MP * 2 * 4);
     const size_t o_datt = cv.take(MP * d * esz), o_dq = cv.take(B * d * esz), o_dh = cv.take(MP * F * esz);
+    const size_t o_dqe = c->cross_es ? cv.take(B * H * d * 4) : 0, o_dctx = c->cross_es ? cv.take(MP * H * d * esz) : 0;
     const size_t o_cpart = cv.take(B * c->cross_splits * d * 4), o_cml = cv.take(B * c->cross_splits * H * 2 * 4);
     const size_t o_pv = cv.take(MP * (n_tiles + 4) * 4), o_pi = cv.take(MP * (n_tiles + 4) * 4);  // [part][mpad]
     const size_t o_feed = cv.take(B * c->tok_ld * 4), o_out = cv.take(B * c->tok_ld * 4);
@@ -808,6 +848,7 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     c->vT = w + o_vT; c->att = w + o_att; c->hbuf = w + o_h; c->enc_out = w + o_enc; c->enc_out_f32 = (float*)(w + o_encf);
     c->cross_kv = w + o_ckv; c->self_k = w + o_sk; c->self_v = w + o_sv;
     if (f8) { c->cross_kv8 = w + o_ckv8; c->kv_amax = (float*)(w + o_kvam); }
+    if (c->cross_es) { c->es_E = w + o_ckv; c->cross_kv = nullptr; c->dqe = (float*)(w + o_dqe); c->dctx = w + o_dctx; }
     if (c->enc_fold) { c->xb = w + o_xb; c->enc_part = (float*)(w + o_epart); c->enc_stat = (float*)(w + o_estat); }
     if (c->mx_ok) {
         c->xn8 = (unsigned char*)(w + o_xn8); c->xn8_sc = (unsigned char*)(w + o_xn8s);
@@ -867,6 +908,8 @@ void wh_ctx_free(wh_ctx* c) {
     if (c->logits) hipFree(c->logits);
     delete c;
 }
+
+int wh_ctx_cross_mode(const wh_ctx* c) { return c ? (c->cross_es ? 1 : 0) : -1; }
 
 const char* wh_last_error(const wh_ctx* c) { return c ? c->err.c_str() : wh_global_error().c_str(); }
 

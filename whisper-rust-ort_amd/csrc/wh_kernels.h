@@ -165,6 +165,11 @@ void wh_launch_dec_self_attn(hipStream_t s, int prec, const void* qkv, void* kc,
 void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void* ck, const void* cv, float* part,
                               float* ml, int S, int d, int n_heads, int splits, int B, void* out, int mpad, bool stream_nt);
 
+// wh_cross_es.hip: the same attention computed on the encoder states themselves (bf16, whisper-base geometry): qe [B][H][d] f32
+// expanded queries, E [B][S][d] bf16, out = the H * d context values per clip as a decode-GEMM operand (slab layout, pitch mpad)
+bool wh_cross_es_geometry(int d, int n_heads, int S);
+void wh_launch_dec_cross_attn_es(hipStream_t s, const float* qe, const void* E, void* out, int S, int B, int mpad, bool stream_nt);
+
 // dynamic LDS to request for a cross-attention launch of total_wgs workgroups whose kernel needs own_bytes: caps the resident
 // workgroups per CU at two for large launches (wh_decode.hip)
 size_t wh_cross_lds_reserve(long total_wgs, size_t own_bytes);
