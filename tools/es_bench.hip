@@ -26,6 +26,8 @@ int main(int argc, char** argv) {
     hipMemcpy(q, hq.data(), hq.size() * 4, hipMemcpyHostToDevice);
     hipStream_t s; hipStreamCreate(&s);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipMalloc((void**)&wh_es_bench_dbg, 64 * 8);
+    hipMemset(wh_es_bench_dbg, 0, 64 * 8);
     for (int nt = 1; nt >= 0; nt--) {
         for (int i = 0; i < 3; i++) wh_launch_dec_cross_attn_es(s, q, E, out, S, B, mpad, nt);
         hipEventRecord(e0, s);
@@ -35,6 +37,15 @@ int main(int argc, char** argv) {
         float ms = 0; hipEventElapsedTime(&ms, e0, e1);
         const double us = ms * 1e3 / reps, bytes = (double)B * S * d * 2;
         printf("clips %d nt %d: %.1f us per launch, %.2f TB/s (%s)\n", B, nt, us, bytes / us * 1e-6, hipGetErrorString(hipGetLastError()));
+    }
+    if ((getenv("WH_ES_ABL") && atoi(getenv("WH_ES_ABL")) == 2) || (getenv("WH_ES_ABL2") && (atoi(getenv("WH_ES_ABL2")) & 2))) {
+        unsigned long long h[64];
+        hipMemcpy(h, wh_es_bench_dbg, sizeof h, hipMemcpyDeviceToHost);
+        const double n = (double)h[5];
+        printf("consumer wave 0 of workgroup 0, cycles per tile over %.0f tiles: wait+barrier %.0f | LDS reads landed %.0f | softmax %.0f | score MFMA + exchange %.0f | transpose + output MFMA %.0f\n",
+               n, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n);
+        const double nl = (double)h[11];
+        printf("loader wave: vmcnt wait %.0f | barrier %.0f | issue %.0f cycles per tile\n", h[8] / nl, h[9] / nl, h[10] / nl);
     }
     return 0;
 }

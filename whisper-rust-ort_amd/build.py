@@ -21,7 +21,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-pthread", "-Wa
 # wh_attn.hip: the softmax maxima never see a NaN that matters (a NaN score poisons its row either way); without
 # this every fmaxf operand is canonicalised first (v_max_f32 x, x, x), which doubles the max instructions of a loop
 # that is VALU-bound.  Infinities keep their meaning (-inf masks the tail keys).
-EXTRA_FLAGS = {"wh_attn.hip": ["-fno-honor-nans"]}
+EXTRA_FLAGS = {"wh_attn.hip": ["-fno-honor-nans"], "wh_cross_es.hip": ["-fno-honor-nans"]}   # (the same for the running maxima of wh_cross_es.hip)
 
 
 def _stale(target: str, deps) -> bool:

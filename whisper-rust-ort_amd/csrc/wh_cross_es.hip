@@ -14,28 +14,35 @@
 // instead of 8 x 64) — 25 GFLOP per launch at 1024 clips, which is why it runs on the matrix cores:
 //
 //   scores  D[m][key] = sum_dim  QE[m][dim] * E[key][dim]     mfma 16x16x32 bf16, rows m = {hi(qe_h) : h} ++ {lo(qe_h) : h}
-//   output  C[m][dim] = sum_key  P[m][key]  * E[key][dim]     mfma 16x16x32 bf16, rows m = {hi(p_h)} ++ {lo(p_h)}
+//   output  C[m][dim] = sum_key  P[m][key]  * E[key][dim]     mfma 16x16x32 bf16, rows m = {bf16(p_h) : h} ++ zeros
 //
-// Both row operands are split into a bf16 head and a bf16 remainder (x = hi + lo to ~16 mantissa bits): the 8 heads fill
-// only half of a 16-row MFMA tile, the other half carries the remainders for free, and neither the expanded query nor the
-// probabilities lose precision to bf16 — the only rounded quantity is E, which the projected form rounds as its GEMM operand
-// as well.
+// The expanded queries are split into a bf16 head and a bf16 remainder (qe = hi + lo to ~16 mantissa bits): the 8 heads fill
+// only half of a 16-row MFMA tile, the other half carries the remainders for free, so the scores see no bf16 rounding of the
+// query side; the only rounded operand is E, which the projected form rounds as its GEMM operand as well.  The probabilities go
+// in as bf16 (their remainder would vanish in the bf16 rounding of the output).
 //
-// One workgroup (4 waves) per clip.  E streams global -> LDS on the LDS-DMA path (global_load_lds_dwordx4, no registers)
-// through a ring of four 32-key tiles (32 KiB each; three in flight while one is consumed); per tile:
-//   A: counted vmcnt wait + barrier (tile visible)            | issue the tile three ahead into the slot just freed
-//   scores: wave w -> keys 16 (w / 2) .. + 15, dims 256 (w % 2) .. + 255: 8 ds_read_b128 + 8 MFMA, hi + lo rows added across
-//           lanes (v_permlane32_swap), partial scores to LDS
-//   B: barrier
-//   every wave: all 8 x 32 scores (two dim halves added), online softmax (running max / sum per head; identical in the four
-//           waves), P operand built in registers, accumulators rescaled
-//   output: wave w -> dims 128 w .. + 127: a lane reads 8 keys x 8 dims as 8 ds_read_b128 and transposes the 8 x 8 block in
-//           registers (32 v_perm_b32) into the 8 key-contiguous column operands; 8 MFMA
+// One workgroup per CU (persistent, walks its clips): four computing waves + loader wave(s).  E streams global -> LDS on the
+// LDS-DMA path (global_load_lds_dwordx4, no registers) through a ring of four 32-key tiles (32 KiB each), every piece issued by
+// a loader wave; one barrier per tile; iteration g (tile g + 1 landed, two tiles in flight behind it):
+//   scores of tile g + 1: wave w -> keys 16 (w / 2) .. + 15, dims 256 (w % 2) .. + 255: 8 ds_read_b128 + 8 MFMA, hi + lo rows added
+//           across lanes (v_permlane32_swap), partial scores to the LDS exchange buffer of tile g + 1
+//   softmax of tile g (every wave, identically — each needs the whole 16 x 32 probability operand): the two dim halves of the
+//           8 x 32 scores added, running max / sum per head, operand built in registers, accumulators rescaled when a maximum
+//           moved (factors through v_readlane)
+//   output of tile g: wave w -> dims 128 w .. + 127: a lane reads 8 keys x 8 dims as 8 ds_read_b128 and transposes the 8 x 8 block
+//           in registers (32 v_perm_b32) into the 8 key-contiguous column operands; 8 MFMA
 // Bank conflicts: LDS is written linearly by the DMA, so the swizzle is on the source side — LDS chunk p of tile row r holds
-// dim-chunk p ^ (r & 15); both read patterns then hit 16 distinct 16-byte slots per service group (the key order inside a
-// 32-deep contraction step is (fg & 1) * 16 + (fg >> 1) * 8 + j for the same reason).
-// No cross-wave merge at the end: every wave has seen every key and owns its own 128 output dims.
+// dim-chunk p ^ (r & 15); both read patterns then hit 16 distinct 16-byte slots per ds_read_b128 service group (the key order
+// inside a 32-deep contraction step is (fg & 1) * 16 + (fg >> 1) * 8 + j for the same reason).
+// No cross-wave merge at the end of a clip: every wave has seen every key and owns its own 128 output dims.
+//
+// Measured (MI355X, 1024 clips per launch, inside bench.py's step): 250 us = 6.3 TB/s = 0.79 of the HBM roof; the ring alone
+// (no arithmetic) streams at 6.7 TB/s = 236 us.  The difference is instruction issue of the four computing waves (one per SIMD,
+// ~1,850 cycles per tile at the ~1.4 GHz the chip holds under this load against ~1,650 for the stream): records in DESIGN.md
+// section 5d and tools/cross_es2_proto.hip.txt (a form with the softmax shared through LDS: three barriers per 64 keys, no faster).
 #include <stdlib.h>
+
+#include <algorithm>
 
 #include "wh_common.h"
 #include "wh_kernels.h"
@@ -45,11 +52,11 @@ namespace {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-constexpr int ES_D = 512, ES_H = 8, ES_TK = 32;
+constexpr int ES_D = 512, ES_H = 8, ES_TK = 32, ES_NSTAGE = 4;
 constexpr int ES_ROWB = ES_D * 2;                      // bytes per key row
 constexpr int ES_TILEB = ES_TK * ES_ROWB;              // 32 KiB
 constexpr int ES_SCP = 36;                             // floats per (dim half, head) row of the score exchange (32 keys + pad)
-constexpr int es_lds(int nstage, bool persist) { return nstage * ES_TILEB + 2 * 2 * ES_H * ES_SCP * 4 + (persist ? ES_H * ES_D * 4 : 0); }
+constexpr int ES_LDS = ES_NSTAGE * ES_TILEB + 2 * 2 * ES_H * ES_SCP * 4 + ES_H * ES_D * 4;   // ring + score exchange + next queries = 148.5 KiB
 
 template <int N> __device__ __forceinline__ void es_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -65,110 +72,126 @@ __device__ __forceinline__ float es_sum32(float v) {   // v(lane) + v(lane ^ 32)
 
 // qe : [B][8][512] f32 expanded queries (natural-log score units)        E: [B][S][512] bf16 encoder states (final LayerNorm applied)
 // out: ctx as the decode GEMM's operand, slab layout [8 * 512 / 32][mpad][32] bf16, column h * 512 + dim
-// NSTAGE ring slots: NSTAGE - 1 tiles in flight while one is consumed (4: 130 KiB, one workgroup per CU; 2: 66 KiB, two per CU).
-// PERSIST: a workgroup walks clips blockIdx.x, + gridDim.x, ... with ONE tile sequence over all of them — the ring keeps
-// streaming across a clip boundary (the next clip's first tiles are in flight while this clip's last are consumed) and the
-// next clip's expanded queries arrive through LDS (a 16 KiB DMA issued a clip ahead), so a CU's stream never drains between
-// clips; without it every workgroup pays its own start-up (query loads, first-tile latency) and its tail.
-template <int AUX, int NSTAGE, bool PERSIST, int ABL = 0>   // ABL (tools/es_bench.hip only): 1 = ring, waits and barriers only
-__global__ __launch_bounds__(256, 1) void k_dec_cross_attn_es(const float* __restrict__ qe, const bf16* __restrict__ E,
-                                                                                bf16* __restrict__ out, int S, int mpad, int B) {
+//
+// Roles.  Waves 0-3 compute; waves 4 .. 3 + NL only load: every LDS-DMA piece of the ring and of the query prefetch is issued by
+// a loader wave.  An LDS-DMA wave-instruction costs its issuer 60-185 cycles when it sits among ds_reads and MFMAs
+// (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"): with the four computing waves issuing their own eight pieces per tile the
+// kernel ran at 253 us per 1024-clip launch against 236 us for the ring alone.  All waves meet at the same barriers.
+//
+// A workgroup walks clips blockIdx.x, + gridDim.x, ... with ONE tile sequence over all of them: the ring keeps streaming across a
+// clip boundary (the next clip's first tiles are in flight while this clip's last are consumed) and the next clip's expanded
+// queries arrive through LDS a clip ahead, so a CU's stream never drains between clips.
+//
+// Software pipeline, one barrier per tile: iteration g computes the SCORES of tile g + 1 and the softmax + output of tile g, so
+// the LDS round trips and MFMA chains of the two halves overlap inside a wave and the score exchange needs no barrier of its
+// own.  Tile g + 1 must therefore have landed at the top of iteration g: NSTAGE - 2 tiles stay in flight.
+template <int AUX, int NL, int ABL = 0>   // ABL (tools/es_bench.hip only): 1 = ring, waits and barriers only; 2 = phase stamps (s_memtime) of workgroup 0 into dbg
+__global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es(const float* __restrict__ qe, const bf16* __restrict__ E,
+                                                                         bf16* __restrict__ out, int S, int mpad, int B, unsigned long long* dbg) {
+    constexpr int NSTAGE = ES_NSTAGE, LA = NSTAGE - 1;   // LA tiles staged ahead of the one being consumed
+    static_assert(NSTAGE == 4 && (NL == 1 || NL == 2), "ring of four 32-key slots; one or two loader waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sc = reinterpret_cast<float*>(smem + NSTAGE * ES_TILEB);   // [2 tiles][2 dim halves][8 heads][ES_SCP]
-    float* Qs = sc + 2 * 2 * ES_H * ES_SCP;                               // PERSIST: [8][512] f32, the next clip's expanded queries
+    float* Qs = sc + 2 * 2 * ES_H * ES_SCP;                               // [8][512] f32: the next clip's expanded queries
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fl = lane & 15, fg = lane >> 4;
     const int ntile = (S + ES_TK - 1) / ES_TK;
-    const int hf = wave & 1, kt = wave >> 1;
     const int G = gridDim.x;
-    const int n_my = PERSIST ? (B - (int)blockIdx.x + G - 1) / G : 1;   // clips of this workgroup
-    const int total = n_my * ntile;                                      // tiles of this workgroup
-    static_assert(NSTAGE >= 3, "the pipeline holds two tiles (scored / consumed) and needs at least one in flight");
-    constexpr int LA = NSTAGE - 1;   // tiles staged ahead of the one being consumed
+    const int n_my = (B - (int)blockIdx.x + G - 1) / G;   // clips of this workgroup
+    const int total = n_my * ntile;                        // tiles of this workgroup
 
-    // ---- the ring: wave w brings rows 8 w .. 8 w + 7 of a tile, one wave-instruction = one 1 KiB key row.  Tiles are staged
-    // strictly in sequence, so the (clip, tile-in-clip) of the next one to stage is carried along instead of divided out.
-    int st_clip = blockIdx.x, st_t = 0, st_slot = 0;
-    int voff[8];   // byte offset of this lane's 16 bytes of row 8 wave + j inside a tile's 32 KiB of E (the same for every tile: 32 % 16 == 0)
+    if (wave >= 4) {
+        // ================================ loader ================================
+        constexpr int PPT = ES_TK / NL;          // pieces (1 KiB key rows) per loader wave and tile
+        constexpr int QPP = 16 / NL;             // pieces of a clip's 16 KiB of queries per loader wave
+        const int lw = wave - 4;
+        int voff[PPT];   // byte offset of this lane's 16 bytes of row lw * PPT + j inside a tile (the same for every tile: 32 % 16 == 0)
 #pragma unroll
-    for (int j = 0; j < 8; j++) voff[j] = (wave * 8 + j) * ES_ROWB + ((lane ^ ((wave * 8 + j) & 15)) << 4);
-    auto stage_next = [&]() {
-        char* base = smem + st_slot * ES_TILEB;
-        const char* Et = reinterpret_cast<const char*>(E) + ((long)st_clip * S + (long)st_t * ES_TK) * ES_ROWB;   // wave-uniform
-        if (st_t * ES_TK + ES_TK <= S) {
+        for (int j = 0; j < PPT; j++) voff[j] = (lw * PPT + j) * ES_ROWB + ((lane ^ ((lw * PPT + j) & 15)) << 4);
+        int st_clip = blockIdx.x, st_t = 0, st_slot = 0;   // tiles are staged strictly in sequence
+        auto stage_next = [&]() {
+            char* base = smem + st_slot * ES_TILEB;
+            const char* Et = reinterpret_cast<const char*>(E) + ((long)st_clip * S + (long)st_t * ES_TK) * ES_ROWB;   // wave-uniform
+            if (st_t * ES_TK + ES_TK <= S) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) es_glds16<AUX>(Et + voff[j], base + (wave * 8 + j) * ES_ROWB);
-        } else {   // the clip's last tile: rows past the end re-read the last key (finite; their scores are masked)
+                for (int j = 0; j < PPT; j++) es_glds16<AUX>(Et + voff[j], base + (lw * PPT + j) * ES_ROWB);
+            } else {   // the clip's last tile: rows past the end re-read the last key (finite; their scores are masked)
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int r = wave * 8 + j;
-                const int key = min(st_t * ES_TK + r, S - 1);
-                es_glds16<AUX>(reinterpret_cast<const char*>(E) + ((long)st_clip * S + key) * ES_ROWB + ((lane ^ (r & 15)) << 4), base + r * ES_ROWB);
+                for (int j = 0; j < PPT; j++) {
+                    const int r = lw * PPT + j;
+                    const int key = min(st_t * ES_TK + r, S - 1);
+                    es_glds16<AUX>(reinterpret_cast<const char*>(E) + ((long)st_clip * S + key) * ES_ROWB + ((lane ^ (r & 15)) << 4), base + r * ES_ROWB);
+                }
             }
-        }
-        st_slot = st_slot + 1 == NSTAGE ? 0 : st_slot + 1;
-        if (++st_t == ntile) { st_t = 0; st_clip += G; }
-    };
-    // expanded queries of clip `clip` into Qs: 16 KiB, four wave-instructions per wave
-    auto stage_q = [&](int clip) {
-        const float* src = qe + (long)clip * (ES_H * ES_D);
+            st_slot = st_slot + 1 == NSTAGE ? 0 : st_slot + 1;
+            if (++st_t == ntile) { st_t = 0; st_clip += G; }
+        };
+        auto stage_q = [&](int clip) {
+            const float* src = qe + (long)clip * (ES_H * ES_D);
 #pragma unroll
-        for (int j = 0; j < 4; j++) es_glds16<0>(src + ((wave * 4 + j) * 64 + lane) * 4, reinterpret_cast<char*>(Qs) + (wave * 4 + j) * 1024);
-    };
-
-    // ---- expanded queries of this wave's dim half as the MFMA row operand: row fl -> head fl & 7, rows 8..15 the remainders
-    bf16x8 qa[8];
-    f32x4 qraw[16];
-    auto build_qa = [&]() {
-        const bool lo = fl >= 8;
-#pragma unroll
-        for (int s = 0; s < 8; s++) {
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const float v = qraw[2 * s + (u >> 2)][u & 3] * 1.44269504088896341f;   // scores in log2 units: p = exp2(s - m)
-                const bf16 h = (bf16)v;
-                qa[s][u] = lo ? (bf16)(v - (float)h) : h;
-            }
-        }
-    };
-    auto qa_from_lds = [&]() {
-        const float* qp = Qs + (fl & 7) * ES_D + 256 * hf + 8 * fg;
-#pragma unroll
-        for (int s = 0; s < 8; s++) {
-            qraw[2 * s] = *reinterpret_cast<const f32x4*>(qp + 32 * s);
-            qraw[2 * s + 1] = *reinterpret_cast<const f32x4*>(qp + 32 * s + 4);
-        }
-        build_qa();
-    };
-    if constexpr (PERSIST) {
+            for (int j = 0; j < QPP; j++) es_glds16<0>(src + ((lw * QPP + j) * 64 + lane) * 4, reinterpret_cast<char*>(Qs) + (lw * QPP + j) * 1024);
+        };
         stage_q(blockIdx.x);
 #pragma unroll
         for (int t = 0; t < LA; t++)
             if (t < total) stage_next();
-        if (total >= LA) es_wait_vm<8 * LA>(); else es_wait_vm<0>();   // this wave's share of the queries (issued first: vmcnt retires in order)
-        __builtin_amdgcn_s_barrier();                                    // ... and everybody else's
-        qa_from_lds();
-    } else {
-        // (issued by hand: the compiler would sink plain loads below the ring's first stages and then wait for everything)
-        const float* qp = qe + ((long)blockIdx.x * ES_H + (fl & 7)) * ES_D + 256 * hf + 8 * fg;
-#define WH_ES_QLD(I, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=&v"(qraw[I]) : "v"(qp) : "memory")
-        WH_ES_QLD(0, 0);    WH_ES_QLD(1, 16);   WH_ES_QLD(2, 128);  WH_ES_QLD(3, 144);
-        WH_ES_QLD(4, 256);  WH_ES_QLD(5, 272);  WH_ES_QLD(6, 384);  WH_ES_QLD(7, 400);
-        WH_ES_QLD(8, 512);  WH_ES_QLD(9, 528);  WH_ES_QLD(10, 640); WH_ES_QLD(11, 656);
-        WH_ES_QLD(12, 768); WH_ES_QLD(13, 784); WH_ES_QLD(14, 896); WH_ES_QLD(15, 912);
-#undef WH_ES_QLD
-#pragma unroll
-        for (int t = 0; t < LA; t++) stage_next();
-        // the 16 query loads were issued first: done when at most the 8 LA ring loads are outstanding
-        asm volatile("s_waitcnt vmcnt(%16)"
-                     : "+v"(qraw[0]), "+v"(qraw[1]), "+v"(qraw[2]), "+v"(qraw[3]), "+v"(qraw[4]), "+v"(qraw[5]), "+v"(qraw[6]), "+v"(qraw[7]),
-                       "+v"(qraw[8]), "+v"(qraw[9]), "+v"(qraw[10]), "+v"(qraw[11]), "+v"(qraw[12]), "+v"(qraw[13]), "+v"(qraw[14]), "+v"(qraw[15])
-                     : "n"(8 * LA) : "memory");
-        build_qa();
+        // vmcnt retires in issue order (and holds at most 63): "all but the last two tiles' pieces" covers the queries and tile 0
+        if (total >= LA) es_wait_vm<(PPT * (LA - 1) < 63 ? PPT * (LA - 1) : 63)>(); else es_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();   // P1: the first clip's queries are in Qs
+        __builtin_amdgcn_s_barrier();   // P2: tile 0 is in the ring
+        int clip = blockIdx.x, t = 0;
+        unsigned long long lt[4] = {0, 0, 0, 0};
+        for (int g = 0; g < total; g++) {
+            unsigned long long c0 = 0, c1 = 0, c2 = 0;
+            if constexpr (ABL & 2) c0 = __builtin_amdgcn_s_memtime();
+            if (g + 1 < total) {   // tile g + 1 has landed; the younger tiles stay in flight.  Conservative where the next clip's
+                                   // queries are among the younger loads: the count then also covers a few pieces of tile g + 2.
+                if (total - 2 - g >= LA - 2) es_wait_vm<PPT*(LA - 2)>(); else es_wait_vm<0>();
+            }
+            if constexpr (ABL & 2) c1 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            if constexpr (ABL & 2) c2 = __builtin_amdgcn_s_memtime();
+            if (g + LA < total) stage_next();
+            if (t == 0 && clip + G < B) stage_q(clip + G);   // Qs was read (if at all) before this barrier
+            if (++t == ntile) { t = 0; clip += G; }
+            if constexpr (ABL & 2) { lt[0] += c1 - c0; lt[1] += c2 - c1; lt[2] += __builtin_amdgcn_s_memtime() - c2; lt[3] += 1; }
+        }
+        if constexpr (ABL & 2) {
+            if (blockIdx.x == 0 && lane == 0 && dbg) { for (int i = 0; i < 4; i++) dbg[8 + 4 * (wave - 4) + i] = lt[i]; }
+        }
+        return;
     }
 
-    // ---- scores of tile (slot `sl`) for keys 16 kt + fl over dims 256 hf ..: rows 4 fg + i of D; partials to sc buffer `buf`
+    // ================================ compute ================================
+    const int fl = lane & 15, fg = lane >> 4;
+    const int hf = wave & 1, kt = wave >> 1;
+    // ---- expanded queries of this wave's dim half as the MFMA row operand: row fl -> head fl & 7, rows 0-7 the bf16 heads,
+    // rows 8-15 the bf16 remainders (qe = hi + lo to ~16 mantissa bits)
+    bf16x8 qa[8];
+    auto qa_from_lds = [&]() {
+        const float* qp = Qs + (fl & 7) * ES_D + 256 * hf + 8 * fg;
+        const bool lo = fl >= 8;
+#pragma unroll
+        for (int s0 = 0; s0 < 8; s0 += 4) {   // eight reads in flight at a time (left alone, the compiler keeps two)
+            f32x4 q[4][2];
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                q[s][0] = *reinterpret_cast<const f32x4*>(qp + 32 * (s0 + s));
+                q[s][1] = *reinterpret_cast<const f32x4*>(qp + 32 * (s0 + s) + 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const float v = q[s][u >> 2][u & 3] * 1.44269504088896341f;   // scores in log2 units: p = exp2(s - m)
+                    const bf16 h = (bf16)v;
+                    qa[s0 + s][u] = lo ? (bf16)(v - (float)h) : h;
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // ---- scores of the tile in slot `sl` for keys 16 kt + fl over dims 256 hf ..: rows 4 fg + i of D; partials to sc buffer `buf`
     auto score_reads = [&](int sl, bf16x8 (&ef)[8]) {
         const int r = 16 * kt + fl;
         const char* rp = smem + sl * ES_TILEB + r * ES_ROWB;
@@ -196,35 +219,29 @@ __global__ __launch_bounds__(256, 1) void k_dec_cross_attn_es(const float* __res
         }
     };
 
-    f32x4 acc[8];
+    f32x4 acc[8];   // rows 4 fg + i: heads 4 fg + i in lane groups 0 and 1 (the P operand's rows 8-15 are zero)
     float m_run = -INFINITY, l_run = 0.0f;
     const int kb = 16 * (fg & 1) + 8 * (fg >> 1);   // first key (within a tile) of this lane's contraction slots
     int clip = blockIdx.x, t = 0, slot = 0;          // the tile being consumed: tile t of `clip`, ring slot `slot`
 
-    // Software pipeline, one barrier per tile: iteration g computes the SCORES of tile g + 1 and the softmax + output of tile g,
-    // so the LDS round trips and MFMA chains of the two halves overlap inside a wave (one wave per SIMD: nobody else hides them)
-    // and the score exchange needs no barrier of its own — the barrier at the top of iteration g + 1 publishes it.
-    // Tile g + 1 must therefore have landed at the top of iteration g: LA - 1 tiles stay in flight.
-    {   // scores of tile 0
+    __builtin_amdgcn_s_barrier();   // P1
+    qa_from_lds();
+    __builtin_amdgcn_s_barrier();   // P2
+    if constexpr (!(ABL & 1)) {     // scores of tile 0
         bf16x8 ef[8];
-        if (total > 1) es_wait_vm<8 * (LA - 1)>(); else es_wait_vm<0>();
-        __builtin_amdgcn_s_barrier();
-        if constexpr (!(ABL & 1)) { score_reads(0, ef); score_mfma(ef, 0); }
+        score_reads(0, ef);
+        score_mfma(ef, 0);
     }
 #pragma unroll
     for (int e = 0; e < 8; e++) acc[e] = f32x4{0, 0, 0, 0};
+    unsigned long long ct[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int g = 0; g < total; g++) {
         const bool more = g + 1 < total;
-        if (more) {   // tile g + 1 has landed (this wave's share); the younger tiles stay in flight.  Conservative where other loads
-                      // (the next clip's queries) are among the younger ones: the count then also covers a few loads of tile g + 2.
-            const int newer = min(LA - 2, total - 2 - g);
-            if (newer >= 1) es_wait_vm<8>();
-            else es_wait_vm<0>();
-        }
+        unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+        if constexpr (ABL & 2) c0 = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // tile g + 1 and the scores of tile g visible to all; every wave is done with tile g - 1
-        if (g + LA < total) stage_next();
-        if (PERSIST && t == 0 && clip + G < B) stage_q(clip + G);
+        if constexpr (ABL & 2) c1 = __builtin_amdgcn_s_memtime();
         const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
         if constexpr (ABL & 1) {
             slot = nslot;
@@ -232,16 +249,17 @@ __global__ __launch_bounds__(256, 1) void k_dec_cross_attn_es(const float* __res
             continue;
         }
         // the next clip's first tile is scored with the next clip's queries (in Qs since a clip ago)
-        if (PERSIST && t == ntile - 1 && more) qa_from_lds();
+        if (t == ntile - 1 && more) qa_from_lds();
         const char* tb = smem + slot * ES_TILEB;
-        // ---- every LDS read of this iteration up front: score operands of tile g + 1, scores of tile g, the 8 x 8 blocks of tile g
-        bf16x8 ef[8];
-        if (more) score_reads(nslot, ef);
+        // ---- every LDS read of this iteration up front, in the order of use (LDS returns in order, so each consumer waits only
+        // for what it needs): scores of tile g (softmax), score operands of tile g + 1, the 8 x 8 blocks of tile g (output)
         const int h = fl & 7;
         const float* s0 = sc + (g & 1) * (2 * ES_H * ES_SCP) + h * ES_SCP + kb;
         const float* s1 = s0 + ES_H * ES_SCP;
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(s0), a1 = *reinterpret_cast<const f32x4*>(s0 + 4);
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(s1), b1 = *reinterpret_cast<const f32x4*>(s1 + 4);
+        bf16x8 ef[8];
+        if (more) score_reads(nslot, ef);
         wh_u32x4 blk[8];
         {
             const int cs = (16 * wave + fl);
@@ -251,6 +269,8 @@ __global__ __launch_bounds__(256, 1) void k_dec_cross_attn_es(const float* __res
                 blk[j] = *reinterpret_cast<const wh_u32x4*>(tb + r * ES_ROWB + ((cs ^ (r & 15)) << 4));
             }
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads above the arithmetic below
+        if constexpr (ABL & 2) c2 = __builtin_amdgcn_s_memtime();
         // ---- online softmax of tile g: lane -> head fl & 7, keys kb .. kb + 7 of the tile (identical in the four waves)
         bf16x8 pa;
         {
@@ -269,17 +289,19 @@ __global__ __launch_bounds__(256, 1) void k_dec_cross_attn_es(const float* __res
             const float m_new = fmaxf(m_run, tmax);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
             float ps = 0.0f;
-            const bool lo = fl >= 8;
+            float pv[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const float p = __builtin_amdgcn_exp2f(sv[u] - m_new);   // masked key: exp2(-inf) = 0
-                ps += p;
-                const bf16 ph = (bf16)p;
-                pa[u] = lo ? (bf16)(p - (float)ph) : ph;
+                pv[u] = __builtin_amdgcn_exp2f(sv[u] - m_new);   // masked key: exp2(-inf) = 0
+                ps += pv[u];
             }
+            // rows 0-7 carry bf16(p); rows 8-15 stay zero (a remainder row would be lost in the bf16 rounding of the output anyway)
+            const bool hi = fl < 8;
+#pragma unroll
+            for (int u = 0; u < 8; u++) pa[u] = (bf16)(hi ? pv[u] : 0.0f);
             l_run = l_run * alpha + ps;
             m_run = m_new;
-            // the accumulators hold rows 4 fg + i = heads 4 (fg & 1) + i; head h's factor sits in lane h: through SGPRs (v_readlane),
+            // the accumulators hold rows 4 fg + i = heads 4 fg + i (fg < 2); head h's factor sits in lane h: through SGPRs (v_readlane),
             // and only when some running maximum moved (wave-uniform)
             if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
                 float ah[8];
@@ -294,8 +316,10 @@ __global__ __launch_bounds__(256, 1) void k_dec_cross_attn_es(const float* __res
                 }
             }
         }
+        if constexpr (ABL & 2) { asm volatile("" :: "v"(pa) : "memory"); c3 = __builtin_amdgcn_s_memtime(); }
         // ---- scores of tile g + 1 (independent of everything above: fills the matrix pipe while the VALU transposes)
         if (more) score_mfma(ef, (g + 1) & 1);
+        if constexpr (ABL & 2) { asm volatile("" ::: "memory"); c4 = __builtin_amdgcn_s_memtime(); }
         // ---- output of tile g: dims 128 wave + 8 fl + e, contraction over the tile's 32 keys
 #pragma unroll
         for (int e = 0; e < 8; e++) {
@@ -309,28 +333,27 @@ __global__ __launch_bounds__(256, 1) void k_dec_cross_attn_es(const float* __res
             __builtin_memcpy(&ob, &op, 16);
             acc[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, ob, acc[e], 0, 0, 0);
         }
+        if constexpr (ABL & 2) {
+            asm volatile("" :: "v"(acc[7]) : "memory");
+            ct[0] += c1 - c0; ct[1] += c2 - c1; ct[2] += c3 - c2; ct[3] += c4 - c3; ct[4] += __builtin_amdgcn_s_memtime() - c4; ct[5] += 1;
+        }
         slot = nslot;
         if (++t < ntile) continue;
-        // ---- the clip ends: normalise and store — hi + lo rows, 1 / sum p of the row's head
+        // ---- the clip ends: normalise and store (rows 0-7 = lane groups 0 and 1)
         {
             const float inv = 1.0f / xrow_sum(l_run);
             float ih[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) ih[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv), q));
-            const bool up = fg & 1;
-            const float inv4[4] = {up ? ih[4] : ih[0], up ? ih[5] : ih[1], up ? ih[6] : ih[2], up ? ih[7] : ih[3]};
-            float o[4][8];
-#pragma unroll
-            for (int e = 0; e < 8; e++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) o[i][e] = es_sum32(acc[e][i]) * inv4[i];
             if (fg < 2) {
+                const bool up = fg & 1;
+                const float inv4[4] = {up ? ih[4] : ih[0], up ? ih[5] : ih[1], up ? ih[6] : ih[2], up ? ih[7] : ih[3]};
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int k = (4 * fg + i) * ES_D + 128 * wave + 8 * fl;
                     bf16x8 ov;
 #pragma unroll
-                    for (int e = 0; e < 8; e++) ov[e] = (bf16)o[i][e];
+                    for (int e = 0; e < 8; e++) ov[e] = (bf16)(acc[e][i] * inv4[i]);
                     *reinterpret_cast<bf16x8*>(out + ((long)(k >> 5) * mpad + clip) * 32 + (k & 31)) = ov;
                 }
             }
@@ -343,33 +366,40 @@ __global__ __launch_bounds__(256, 1) void k_dec_cross_attn_es(const float* __res
         t = 0;
         clip += G;
     }
+    if constexpr (ABL & 2) {
+        if (blockIdx.x == 0 && tid == 0 && dbg) { for (int i = 0; i < 6; i++) dbg[i] = ct[i]; }
+    }
 }
 
+
 }  // namespace
+
+#ifdef WH_ES_BENCH
+unsigned long long* wh_es_bench_dbg = nullptr;
+#endif
 
 bool wh_cross_es_geometry(int d, int n_heads, int S) { return d == ES_D && n_heads == ES_H && S >= 4 * ES_TK; }
 
 void wh_launch_dec_cross_attn_es(hipStream_t s, const float* qe, const void* E, void* out, int S, int B, int mpad, bool stream_nt) {
     static const int nt_env = [] { const char* e = getenv("WH_CROSS_NT"); return e ? atoi(e) : -1; }();
-    static const int nstage = [] { const char* e = getenv("WH_ES_NSTAGE"); return e ? atoi(e) : 4; }();     // (A/B runs)
+    static const int nl = [] { const char* e = getenv("WH_ES_LOADERS"); return e ? atoi(e) : 1; }();        // (A/B runs) loader waves per workgroup
     static const int persist = [] { const char* e = getenv("WH_ES_PERSIST"); return e ? atoi(e) : 1; }();   // (A/B runs) 0: one workgroup per clip
     static const int n_cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n; }();
     if (nt_env >= 0) stream_nt = nt_env != 0;
-#define WH_ES_LAUNCH(AUX_, NS_, P_, GRID_, ...)                                                                                        \
-    do {                                                                                                                            \
-        wh_ensure_dyn_lds((const void*)k_dec_cross_attn_es<AUX_, NS_, P_>, es_lds(NS_, P_));                                        \
-        hipLaunchKernelGGL((k_dec_cross_attn_es<AUX_, NS_, P_, ##__VA_ARGS__>), dim3(GRID_), dim3(256), es_lds(NS_, P_), s, qe, (const bf16*)E, (bf16*)out, S, mpad, B); \
-    } while (0)
-    // persistent form: one workgroup per CU walks its clips (only worth it when a CU gets more than one)
+    const int grid = persist ? std::min(B, n_cus) : B;   // one workgroup per CU walks its clips
+    unsigned long long* es_dbg = nullptr;
 #ifdef WH_ES_BENCH
-    if (getenv("WH_ES_ABL")) { WH_ES_LAUNCH(2, 4, true, n_cus, 1); return; }
+    es_dbg = wh_es_bench_dbg;
 #endif
-    if (persist && B > n_cus) {
-        if (nstage == 3) { if (stream_nt) WH_ES_LAUNCH(2, 3, true, n_cus); else WH_ES_LAUNCH(0, 3, true, n_cus); }
-        else { if (stream_nt) WH_ES_LAUNCH(2, 4, true, n_cus); else WH_ES_LAUNCH(0, 4, true, n_cus); }
-        return;
-    }
-    if (nstage == 3) { if (stream_nt) WH_ES_LAUNCH(2, 3, false, B); else WH_ES_LAUNCH(0, 3, false, B); }
-    else { if (stream_nt) WH_ES_LAUNCH(2, 4, false, B); else WH_ES_LAUNCH(0, 4, false, B); }
+#define WH_ES_LAUNCH(AUX_, NL_, ...)                                                                                                \
+    do {                                                                                                                            \
+        wh_ensure_dyn_lds((const void*)k_dec_cross_attn_es<AUX_, NL_, ##__VA_ARGS__>, ES_LDS);                                      \
+        hipLaunchKernelGGL((k_dec_cross_attn_es<AUX_, NL_, ##__VA_ARGS__>), dim3(grid), dim3(256 + 64 * NL_), ES_LDS, s, qe, (const bf16*)E, (bf16*)out, S, mpad, B, es_dbg); \
+    } while (0)
+#ifdef WH_ES_BENCH
+    if (const char* e = getenv("WH_ES_ABL")) { if (atoi(e) == 2) WH_ES_LAUNCH(2, 1, 2); else WH_ES_LAUNCH(2, 1, 1); return; }
+#endif
+    if (nl == 2) { if (stream_nt) WH_ES_LAUNCH(2, 2); else WH_ES_LAUNCH(0, 2); }
+    else { if (stream_nt) WH_ES_LAUNCH(2, 1); else WH_ES_LAUNCH(0, 1); }
 #undef WH_ES_LAUNCH
 }
