@@ -538,6 +538,8 @@ def main() -> None:
                        "pipeline": ({"enc_cus": a.enc_cus or "all", "dec_cus": a.dec_cus or "all",
                                      "note": "step i's token loop and step i+1's log-mel + encoder run side by side on disjoint compute units; "
                                              "every timed step executes one encoder pass and one decode pass"} if a.pipeline else None),
+                       "cross_attention": ("on the encoder states (k_dec_cross_attn_es: S x d bf16 per clip, layer and token; K / V projections folded into "
+                                           "the decode GEMMs around it)" if cross_es else "on the projected K / V cache (2 S x d per clip, layer and token)"),
                        "gather": backend, "results_gathered": n_results, "row_check": row_check},
             "rtf": elapsed / audio_s,   # reference definition: latency / duration (src/main.rs:1191)
             "clips_per_s": a.clips * a.steps * world / elapsed,

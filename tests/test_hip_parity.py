@@ -600,3 +600,68 @@ def test_pipelined_device_entry_equals_plain(gpu, masks):
         ctx.close()
         hip.free(da)
         hip.free(db)
+
+
+# ------------------------------------------------------------------------------------------------
+# cross-attention on the encoder states (wh_cross_es.hip): the same attention as the projected K / V form
+# (reference: present.{i}.encoder.{key,value} computed once per clip, src/main.rs:771-787, read by every token, :798-812)
+# ------------------------------------------------------------------------------------------------
+def test_cross_mode_rule_and_flags(gpu):
+    """What a context's token loop streams is decided from the model and the context only: bf16 whisper-base geometry and
+    max_batch >= 256 -> the encoder states; everything else -> the projected K / V cache.  The flags override the size rule;
+    forcing the encoder-state form onto a model without the geometry is refused."""
+    base16 = wb.Model("synthetic:base:1234", 0, wb.WH_PREC_BF16)
+    for mb, want in ((1, 0), (64, 0), (256, 1)):
+        c = wb.Context(base16, mb)
+        assert c.cross_mode == want, (mb, c.cross_mode)
+        c.close()
+    c = wb.Context(base16, 2, cross_es=True)
+    assert c.cross_mode == 1
+    c.close()
+    c = wb.Context(base16, 256, cross_es=False)
+    assert c.cross_mode == 0
+    c.close()
+    nano = wb.Model("synthetic:nano:7", 0, wb.WH_PREC_BF16)
+    with pytest.raises(wb.WhisperHipError):
+        wb.Context(nano, 4, cross_es=True)
+    base32 = wb.Model("synthetic:base:1234", 0, wb.WH_PREC_F32)
+    c = wb.Context(base32, 256)
+    assert c.cross_mode == 0        # the exact-f32 mode keeps the reference's K / V form
+    c.close()
+
+
+@pytest.mark.parametrize("nb", [32, 288])
+def test_cross_es_matches_projected_kv_and_golden(gpu, golden_dir, nb):
+    """Teacher-forced logits of the same clips on two contexts of one bf16 whisper-base model — cross-attention on the encoder
+    states vs on the projected K / V — against each other and against the f32 golden vectors (clip 0 at row 0).  32 clips: one
+    clip per workgroup; 288: the persistent form, 32 workgroups walk two clips each (ring and query prefetch across a clip
+    boundary), every clip repeated nine times must give identical rows.  The two forms are the same arithmetic up to bf16
+    rounding: their difference stays below each one's distance from the f32 vectors."""
+    g0 = np.load(os.path.join(golden_dir, "base_s1234_c0.npz"))
+    prompt, eot = g0["prompt"].tolist(), int(g0["eot"])
+    forced = g0["forced_c"].tolist()
+    model = wb.Model("synthetic:base:1234", 0, wb.WH_PREC_BF16)
+    distinct = [ms.synth_clip(0), ms.synth_clip(3)] + [ms.synth_clip(300 + i) for i in range(30)]
+    clips = [distinct[i % 32] for i in range(nb)]
+    fp = wb.DecodeParams(prompt, len(forced) + 1, eot, forced=forced)
+    out = {}
+    for name, es in (("es", True), ("kv", False)):
+        ctx = wb.Context(model, nb, cross_es=es)
+        assert ctx.cross_mode == int(es)
+        ctx.transcribe_batch(clips, wb.DecodeParams(prompt, 2, eot, [eot]))
+        t, l = ctx.greedy_decode_resident_batch(fp, want_logits=True)
+        l = np.stack(l)
+        for i in range(32, nb):          # duplicates inside one context: identical arithmetic wherever the clip sits
+            assert np.array_equal(l[i], l[i % 32]), (name, i)
+        out[name] = l[:32]
+        ctx.close()
+    assert np.isfinite(out["es"]).all()
+    d = np.abs(out["es"] - out["kv"]).max(axis=(1, 2))
+    e_es = max(np.abs(out["es"][0][i][g0["top_ids_c"][i]] - g0["top_vals_c"][i]).max() for i in range(len(forced) + 1))
+    e_kv = max(np.abs(out["kv"][0][i][g0["top_ids_c"][i]] - g0["top_vals_c"][i]).max() for i in range(len(forced) + 1))
+    print(f"{nb} clips: encoder-state vs K/V form max |dlogit| {d.max():.4f} (median {np.median(d):.4f}); vs f32 golden: es {e_es:.4f}, kv {e_kv:.4f}")
+    assert d.max() < 0.12                 # measured 0.07-0.08: two bf16 roundings of the same attention (logit std 1.3)
+    assert max(e_es, e_kv) < 0.25         # the bf16-vs-f32 bound of test_bf16_teacher_forced_agreement
+    srt = np.sort(out["kv"], axis=2)
+    decided = (srt[:, :, -1] - srt[:, :, -2]) > 2.0 * d[:, None]
+    assert (out["es"].argmax(axis=2)[decided] == out["kv"].argmax(axis=2)[decided]).all()
