@@ -411,24 +411,28 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 wh_launch_dec_gemm(s, prec, true, a);
             }
             if (c->cross_es) {
-                const long Hd = (long)D.n_heads * d;
-                {   // LN2 ∘ expanded cross-attention queries qe = blockdiag(Wk_h^T) (Wq LN2(x) + bq): [nb][H d] f32
+                // the attention runs on the encoder states (wh_cross_es.hip): W_k moves to the query side, W_v behind the attention
+                {   // LN2 ∘ cross-attention query, kept in f32
                     Prof pr(c, WH_KG_DEC_GEMM);
                     a = SkinnyArgs();
-                    a.X = c->dxs; a.x_mpad = mpad; a.W = L.cqe_w; a.bias = L.cqe_b; a.C = c->dqe; a.ldc = Hd; a.M = nb; a.N = (int)Hd; a.K = (int)d;
-                    a.ln_part = c->lnpart; a.ln_tiles = ln_tiles_d; a.ln_s = L.cqe_s;
+                    a.X = c->dxs; a.x_mpad = mpad; a.W = L.cq_w; a.bias = L.cq_b; a.C = c->dq32; a.ldc = d; a.M = nb; a.N = (int)d; a.K = (int)d;
+                    a.ln_part = c->lnpart; a.ln_tiles = ln_tiles_d; a.ln_s = L.cq_s;
                     wh_launch_dec_gemm(s, prec, true, a);
+                    // expanded queries qe[h] = W_k,h^T q_h: [nb][H][d] f32
+                    wh_launch_dec_qexpand(s, c->dq32, L.cqx_w, c->dqe, nb, (int)d, D.n_heads);
                 }
                 {
                     Prof pr(c, WH_KG_DEC_CROSS_ATTN);
                     wh_launch_dec_cross_attn_es(s, c->dqe, c->es_E, c->dctx, (int)S, nb, mpad, kv_nt);
                 }
-                {   // Wo blockdiag(Wv_h) ctx + (bo + Wo bv) + residual → x, raw slab, LN3 partials
+                {   // per head: W_v,h ctx_h + b_v,h → the attention output the out-projection below expects (slab layout)
                     Prof pr(c, WH_KG_DEC_GEMM);
                     a = SkinnyArgs();
-                    a.X = c->dctx; a.x_mpad = mpad; a.W = L.coe_w; a.bias = L.coe_b; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
-                    a.M = nb; a.N = (int)d; a.K = (int)Hd; a.xslab_out = c->dxs; a.stats_out = c->lnpart;
-                    wh_launch_dec_gemm(s, prec, true, a);
+                    a.X = c->dctx; a.x_mpad = mpad; a.W = L.cv_w; a.bias = L.cv_b; a.C = c->datt; a.c_mpad = mpad;
+                    a.M = nb; a.N = WH_HEAD_DIM; a.K = (int)d;
+                    a.zn = D.n_heads; a.x_zs = (long)(d / 32) * mpad * 32; a.w_zs = (long)WH_HEAD_DIM * d; a.c_zs = (long)(WH_HEAD_DIM / 32) * mpad * 32;
+                    a.bias_zs = WH_HEAD_DIM;
+                    wh_launch_dec_gemm(s, prec, false, a);
                 }
             } else {
             {   // LN2 ∘ cross-attention query
@@ -449,16 +453,16 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                                              (char*)c->cross_kv + (2 * l + 1) * kv_stride * esz, c->cpart, c->cml,
                                              (int)S, (int)d, D.n_heads, c->cross_splits, nb, c->datt, mpad, kv_nt);
             }
+            }
             {   // merge of the key ranges ∘ cross-attention out-proj + residual → x, raw slab, LN3 partials
                 Prof pr(c, WH_KG_DEC_GEMM);
                 a = SkinnyArgs();
-                if (c->cross_splits == 1) a.X = c->datt;  // one key range per clip: the attention kernel wrote its output itself
+                if (c->cross_splits == 1 || c->cross_es) a.X = c->datt;  // one key range per clip: the attention kernel wrote its output itself
                 else { a.xpart = c->cpart; a.xml = c->cml; a.x_splits = c->cross_splits; a.x_heads = D.n_heads; }
                 a.x_mpad = mpad; a.W = L.co_w; a.bias = L.co_b; a.wscale = L.co_sc; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
                 a.M = nb; a.N = (int)d; a.K = (int)d; a.xslab_out = c->dxs; a.stats_out = c->lnpart;
                 if (f8) a.xgamma = L.ln3_w;
                 wh_launch_dec_gemm(s, prec, true, a);
-            }
             }
             {   // LN3 ∘ fc1 + GELU (slab output)
                 Prof pr(c, WH_KG_DEC_GEMM);
@@ -830,6 +834,7 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     const size_t o_dxs = cv.take(MP * d * esz), o_lnp = cv.take((d / 16) * MP * 2 * 4);
     const size_t o_datt = cv.take(MP * d * esz), o_dq = cv.take(B * d * esz), o_dh = cv.take(MP * F * esz);
     const size_t o_dqe = c->cross_es ? cv.take(B * H * d * 4) : 0, o_dctx = c->cross_es ? cv.take(MP * H * d * esz) : 0;
+    const size_t o_dq32 = c->cross_es ? cv.take(B * d * 4) : 0;
     const size_t o_cpart = cv.take(B * c->cross_splits * d * 4), o_cml = cv.take(B * c->cross_splits * H * 2 * 4);
     const size_t o_pv = cv.take(MP * (n_tiles + 4) * 4), o_pi = cv.take(MP * (n_tiles + 4) * 4);  // [part][mpad]
     const size_t o_feed = cv.take(B * c->tok_ld * 4), o_out = cv.take(B * c->tok_ld * 4);
@@ -848,7 +853,7 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     c->vT = w + o_vT; c->att = w + o_att; c->hbuf = w + o_h; c->enc_out = w + o_enc; c->enc_out_f32 = (float*)(w + o_encf);
     c->cross_kv = w + o_ckv; c->self_k = w + o_sk; c->self_v = w + o_sv;
     if (f8) { c->cross_kv8 = w + o_ckv8; c->kv_amax = (float*)(w + o_kvam); }
-    if (c->cross_es) { c->es_E = w + o_ckv; c->cross_kv = nullptr; c->dqe = (float*)(w + o_dqe); c->dctx = w + o_dctx; }
+    if (c->cross_es) { c->es_E = w + o_ckv; c->cross_kv = nullptr; c->dqe = (float*)(w + o_dqe); c->dctx = w + o_dctx; c->dq32 = (float*)(w + o_dq32); }
     if (c->enc_fold) { c->xb = w + o_xb; c->enc_part = (float*)(w + o_epart); c->enc_stat = (float*)(w + o_estat); }
     if (c->mx_ok) {
         c->xn8 = (unsigned char*)(w + o_xn8); c->xn8_sc = (unsigned char*)(w + o_xn8s);

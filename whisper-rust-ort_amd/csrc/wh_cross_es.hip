@@ -372,6 +372,47 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es(const fl
 }
 
 
+
+// ---- expanded queries: qe[m][h][j] = sum_t q[m][64 h + t] * wkT[h][j][t]  (t < 64) ------------------------------------------------
+// The K projection moved to the query side: 8 small products [rows x 64] x [64 x 512] per launch.  One workgroup = 64 rows x one head
+// x 128 columns; the weight tile is the MFMA row operand (a lane ends with 4 consecutive columns of one row: 16-byte stores), q goes
+// in as bf16 hi + lo (two MFMAs per step) so the f32 query is not rounded.  16 KiB of q and 16 KiB of weights per workgroup.
+__global__ __launch_bounds__(256) void k_dec_qexpand(const float* __restrict__ q, const bf16* __restrict__ wkT, float* __restrict__ qe,
+                                                     int M, int d, int n_heads) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fl = lane & 15, fg = lane >> 4;
+    const int h = blockIdx.y, n0 = blockIdx.z * 128;
+    const int m = blockIdx.x * 64 + wave * 16 + fl, mc = min(m, M - 1);
+    bf16x8 xh[2], xl[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+        const float* qp = q + (long)mc * d + h * WH_HEAD_DIM + 32 * ks + 8 * fg;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(qp), b = *reinterpret_cast<const f32x4*>(qp + 4);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const float v = u < 4 ? a[u & 3] : b[u & 3];
+            const bf16 hi = (bf16)v;
+            xh[ks][u] = hi;
+            xl[ks][u] = (bf16)(v - (float)hi);
+        }
+    }
+    const bf16* wp = wkT + ((long)h * d + n0 + fl) * WH_HEAD_DIM + 8 * fg;
+    bf16x8 wf[8][2];
+#pragma unroll
+    for (int nt = 0; nt < 8; nt++)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) wf[nt][ks] = *reinterpret_cast<const bf16x8*>(wp + (long)nt * 16 * WH_HEAD_DIM + 32 * ks);
+#pragma unroll
+    for (int nt = 0; nt < 8; nt++) {
+        f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ks], xl[ks], acc, 0, 0, 0);   // D rows = columns n (4 fg + r), D column = row m (fl)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ks], xh[ks], acc, 0, 0, 0);
+        }
+        if (m < M) *reinterpret_cast<f32x4*>(qe + ((long)m * n_heads + h) * d + n0 + 16 * nt + 4 * fg) = acc;
+    }
+}
+
 }  // namespace
 
 #ifdef WH_ES_BENCH
@@ -402,4 +443,8 @@ void wh_launch_dec_cross_attn_es(hipStream_t s, const float* qe, const void* E, 
     if (nl == 2) { if (stream_nt) WH_ES_LAUNCH(2, 2); else WH_ES_LAUNCH(0, 2); }
     else { if (stream_nt) WH_ES_LAUNCH(2, 1); else WH_ES_LAUNCH(0, 1); }
 #undef WH_ES_LAUNCH
+}
+
+void wh_launch_dec_qexpand(hipStream_t s, const float* q, const void* wkT, float* qe, int M, int d, int n_heads) {
+    hipLaunchKernelGGL(k_dec_qexpand, dim3((M + 63) / 64, n_heads, d / 128), dim3(256), 0, s, q, (const bf16*)wkT, qe, M, d, n_heads);
 }

@@ -173,9 +173,21 @@ __device__ __forceinline__ void load_wfrags(const TW* p, typename FragT<T>::type
     }
 }
 
+// grouped launches (SkinnyArgs::zn): group blockIdx.z works on its own X, W, bias and C
+template <typename T, typename TO, typename TW>
+__device__ __forceinline__ void dec_gemm_group(SkinnyArgs& a) {
+    const long z = blockIdx.z;
+    if (z == 0) return;
+    a.X = (const T*)a.X + z * a.x_zs;
+    a.W = (const TW*)a.W + z * a.w_zs;
+    a.C = (TO*)a.C + z * a.c_zs;
+    if (a.bias) a.bias += z * a.bias_zs;
+}
+
 template <typename T, typename TO, int MT, int NW, int XP, typename TW = T>  // XP > 0: X from XP-bounded attention partials
 __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    dec_gemm_group<T, TO, TW>(a);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fl = lane & 15, fg = lane >> 4;
     const int n0 = blockIdx.x * 16;
@@ -362,6 +374,7 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
 template <typename T, typename TO, int MT, int NT, int NW, typename TW = T>
 __global__ __launch_bounds__(NW * 64, 2) void k_dec_gemm_wide(SkinnyArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    dec_gemm_group<T, TO, TW>(a);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fl = lane & 15, fg = lane >> 4;
     const int n0 = blockIdx.x * 16 * NT;
@@ -1228,12 +1241,12 @@ void launch_dec_gemm_mt(hipStream_t s, const SkinnyArgs& a) {
         // 512 x 512 at 256 rows would leave 64: 5.7 vs 4.1 us), else k_dec_gemm.  Eight waves x 16 tiles of partial sums
         // would take 128 KB of LDS: two tiles at most there.
         int nt = 1;
-        if (NW == 4 && n_tiles % 4 == 0 && (n_tiles / 4) * rg >= 512) nt = 4;
-        else if (n_tiles % 2 == 0 && (n_tiles / 2) * rg >= 128) nt = 2;
+        if (NW == 4 && n_tiles % 4 == 0 && (n_tiles / 4) * rg * a.zn >= 512) nt = 4;
+        else if (n_tiles % 2 == 0 && (n_tiles / 2) * rg * a.zn >= 128) nt = 2;
         if (wide == 2 || (wide == 4 && NW == 4)) nt = wide;
         if (wide != 0 && nt > 1 && n_tiles % nt == 0) {
             const size_t smw = (size_t)NW * WMT * nt * 64 * 16 + (size_t)4 * WMT * 16 * 2 * 4;
-            dim3 gw(n_tiles / nt, rg);
+            dim3 gw(n_tiles / nt, rg, a.zn);
             if (nt == 4) { set_max_smem(k_dec_gemm_wide<T, TO, WMT, 4, NW, TW>, smw); hipLaunchKernelGGL((k_dec_gemm_wide<T, TO, WMT, 4, NW, TW>), gw, dim3(NW * 64), smw, s, a); }
             else { set_max_smem(k_dec_gemm_wide<T, TO, WMT, 2, NW, TW>, smw); hipLaunchKernelGGL((k_dec_gemm_wide<T, TO, WMT, 2, NW, TW>), gw, dim3(NW * 64), smw, s, a); }
             return;
@@ -1241,7 +1254,7 @@ void launch_dec_gemm_mt(hipStream_t s, const SkinnyArgs& a) {
     }
     const int mt = std::min(mt_cap, (a.M + 15) / 16);
     const size_t sm = (size_t)NW * mt * 64 * 16 + (size_t)4 * mt * 16 * 2 * 4;
-    dim3 grid(n_tiles, (a.M + 16 * mt - 1) / (16 * mt));
+    dim3 grid(n_tiles, (a.M + 16 * mt - 1) / (16 * mt), a.zn);
     if (a.xpart) {  // X merged from attention partials: 16-row groups only (the merge is per-lane work)
         dim3 g1(n_tiles, (a.M + 15) / 16);
         const size_t sm1 = (size_t)NW * 64 * 16 + 4 * 16 * 2 * 4 + (size_t)16 * a.K * sizeof(T);  // + merged X tile

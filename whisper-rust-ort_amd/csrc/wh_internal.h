@@ -32,10 +32,10 @@ struct DecLayerDev {
     // LayerNorm's γ is then applied on the activation side (the producers write x ⊙ γ_next into the slab) and
     // *_s hold sum_k γ[k] * W[n][k], *_b hold c[n], both of the dequantised weights
     float *qkv_sc = nullptr, *o_sc = nullptr, *cq_sc = nullptr, *co_sc = nullptr, *fc1_sc = nullptr, *fc2_sc = nullptr;
-    // cross-attention on the encoder states (wh_cross_es.hip, wh_model::cross_es): cqe_w [H d][d] = blockdiag(Wk_h^T) Wq with LN2
-    // folded in (+ cqe_s, cqe_b = c), coe_w [d][H d] = Wo blockdiag(Wv_h), coe_b = bo + Wo bv
-    void *cqe_w = nullptr, *coe_w = nullptr;
-    float *cqe_b = nullptr, *cqe_s = nullptr, *coe_b = nullptr;
+    // cross-attention on the encoder states (wh_cross_es.hip, wh_model::cross_es): cqx_w [H][d][64] = head h's rows of the cross W_k,
+    // transposed (the query-side expansion); cv_w / cv_b = this layer's plain W_v rows and b_v inside the stacked cross-K/V projection
+    void *cqx_w = nullptr, *cv_w = nullptr;
+    float* cv_b = nullptr;
 };
 
 struct wh_model {
@@ -59,7 +59,7 @@ struct wh_model {
     float *cross_kv_s = nullptr, *cross_kv_c = nullptr;
     void* lm_w = nullptr;  // tied embedding ⊙ final-LN γ (LM head operand); WH_PREC_FP8: the embedding itself (γ on the activation side)
     float *lm_s = nullptr, *lm_c = nullptr;
-    bool cross_es = false;   // the decoder layers carry cqe_* / coe_* (bf16, whisper-base geometry)
+    bool cross_es = false;   // the decoder layers carry cqx_w / cv_* (bf16, whisper-base geometry)
     std::vector<EncLayerDev> enc;
     std::vector<DecLayerDev> dec;
     // log-mel tables
@@ -148,6 +148,7 @@ struct wh_ctx {
     // then not allocated); dqe [B][H d] f32 expanded queries; dctx = the H d context values per clip, slab layout
     bool cross_es = false;
     void* es_E = nullptr;
+    float* dq32 = nullptr;      // [B][d] f32 cross-attention queries (pre-scaled)
     float* dqe = nullptr;
     void* dctx = nullptr;
     void* cross_kv8 = nullptr;  // WH_PREC_FP8: the same planes as e4m3 codes (cross_kv is then the bf16 staging copy)

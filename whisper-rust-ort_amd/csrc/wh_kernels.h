@@ -79,6 +79,12 @@ struct SkinnyArgs {
     // raw rows in the compute dtype, slab layout, and this column tile's partial sums
     void* xslab_out = nullptr;   // [N/32][x_mpad][32]
     float* stats_out = nullptr;  // [N/16][x_mpad][2]
+    // grouped form (gridDim.z = zn independent products sharing M, N, K): group z reads X + z * x_zs and W + z * w_zs (elements),
+    // bias + z * bias_zs, and writes C + z * c_zs (elements).  The per-head V projection of the encoder-state cross-attention:
+    // X = head z's 512 context values (16 k-slabs), W = rows 64 z .. of W_v, C = columns 64 z .. of the attention output slab.
+    // (plain consumers only: no LayerNorm fold, residual, statistics or position ticket)
+    int zn = 1;
+    long x_zs = 0, w_zs = 0, c_zs = 0, bias_zs = 0;
     // position advance by the last workgroup of the last kernel of a step
     int* ticket = nullptr;
     int* pos_w = nullptr;
@@ -168,6 +174,9 @@ void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void
 // wh_cross_es.hip: the same attention computed on the encoder states themselves (bf16, whisper-base geometry): qe [B][H][d] f32
 // expanded queries, E [B][S][d] bf16, out = the H * d context values per clip as a decode-GEMM operand (slab layout, pitch mpad)
 bool wh_cross_es_geometry(int d, int n_heads, int S);
+// expanded queries qe[m][h][j] = sum_t q[m][64 h + t] * wkT[h][j][t]: q [M][d] f32 (pre-scaled, bias included), wkT [H][d][64] bf16
+// (head h's rows of W_k, transposed), qe [M][H][d] f32.  q enters the bf16 MFMAs as hi + lo, so nothing of it is rounded.
+void wh_launch_dec_qexpand(hipStream_t s, const float* q, const void* wkT, float* qe, int M, int d, int n_heads);
 void wh_launch_dec_cross_attn_es(hipStream_t s, const float* qe, const void* E, void* out, int S, int B, int mpad, bool stream_nt);
 
 // dynamic LDS to request for a cross-attention launch of total_wgs workgroups whose kernel needs own_bytes: caps the resident

@@ -747,65 +747,22 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
         x.l3b = st.put_f32(T(p + ".final_layer_norm.bias"), d);
     }
     // Cross-attention on the encoder states (wh_cross_es.hip; bf16, whisper-base geometry): the K and V projections move out of the
-    // per-clip cache into the two decode GEMMs around the attention kernel.  Per layer, with Wq' = qs Wq, bq' = qs bq and head h
-    // owning rows 64 h .. 64 h + 63:
-    //   qe[h][j]  = sum_t Wk[64 h + t][j] q[64 h + t]           =>  G[(h, j)][i] = sum_t Wk[64 h + t][j] Wq'[64 h + t][i]   ([H d][d], LN2 folded
-    //                                                                in like cq_w: gamma on the columns, s / c per row; k_proj has no bias)
-    //   out[n]    = bo[n] + sum_r Wo[n][r] (Wv ctx + bv)[r]     =>  Wvo[n][(h, j)] = sum_t Wo[n][64 h + t] Wv[64 h + t][j]   ([d][H d]),
-    //                                                                bias[n] = bo[n] + sum_r Wo[n][r] bv[r]
-    // accumulated in double, rounded once to the compute dtype.
-    struct DecEs { size_t cqe, cqeb, cqes, coe, coeb; };
-    std::vector<DecEs> des(c.dec_layers);
+    // per-clip cache to the query side and the context side of the attention kernel.  Per layer and head h (rows 64 h .. 64 h + 63):
+    //   qe[h][j] = sum_t Wk[64 h + t][j] q[64 h + t]   (k_dec_qexpand)   -> cqx_w = head h's rows of W_k transposed, [H][d][64] (k_proj has no bias)
+    //   out[64 h + t] = sum_j Wv[64 h + t][j] ctx[h][j] + bv[64 h + t]   (grouped decode GEMM) -> the plain W_v rows and b_v of the stacked
+    //   cross-K/V projection (cross_kv_w / cross_kv_b), which stay on the device for the contexts that project K and V
+    // The query projection (LN2 folded, pre-scaled) and the out-projection are the ones the K / V form uses.
+    std::vector<size_t> o_cqx(c.dec_layers, NONE);
     const bool cross_es = m->prec == WH_PREC_BF16 && wh_cross_es_geometry(c.d_model, c.n_heads, c.n_audio_ctx);
     if (cross_es) {
-        const size_t H = c.n_heads, HD = WH_HEAD_DIM, Hd = H * d;
-        std::vector<double> acc(Hd * d);
-        std::vector<float> G(Hd * d), gb(Hd), sv(Hd), cvv(Hd), Wvo(d * Hd), ob(d);
+        const size_t H = c.n_heads, HD = WH_HEAD_DIM;
+        std::vector<float> wkT(H * d * HD);
         for (int i = 0; i < c.dec_layers; i++) {
-            std::string p = dd + ".layers." + std::to_string(i) + ".encoder_attn";
-            const float *Wq = T(p + ".q_proj.weight"), *bq = T(p + ".q_proj.bias"), *Wk = T(p + ".k_proj.weight");
-            const float *Wv = T(p + ".v_proj.weight"), *bv = T(p + ".v_proj.bias"), *Wo = T(p + ".out_proj.weight"), *bo = T(p + ".out_proj.bias");
-            std::fill(acc.begin(), acc.end(), 0.0);
+            const float* Wk = T(dd + ".layers." + std::to_string(i) + ".encoder_attn.k_proj.weight");
             for (size_t h = 0; h < H; h++)
-                for (size_t t = 0; t < HD; t++) {
-                    const float* wq = Wq + (h * HD + t) * d;
-                    const float* wk = Wk + (h * HD + t) * d;
-                    for (size_t j = 0; j < d; j++) {
-                        const double a = (double)wk[j] * (double)qs;
-                        double* row = acc.data() + (h * d + j) * d;
-                        for (size_t k = 0; k < d; k++) row[k] += a * (double)wq[k];
-                    }
-                }
-            for (size_t n = 0; n < Hd * d; n++) G[n] = (float)acc[n];
-            for (size_t h = 0; h < H; h++)
-                for (size_t j = 0; j < d; j++) {
-                    double a = 0.0;
-                    for (size_t t = 0; t < HD; t++) a += (double)Wk[(h * HD + t) * d + j] * (double)bq[h * HD + t] * (double)qs;
-                    gb[h * d + j] = (float)a;
-                }
-            DecEs& x = des[i];
-            x.cqe = st.reserve(Hd * d * m->esz);
-            fold_ln(x.cqe, 0, G.data(), Hd, d, 1.0f, T(dd + ".layers." + std::to_string(i) + ".encoder_attn_layer_norm.weight"),
-                    T(dd + ".layers." + std::to_string(i) + ".encoder_attn_layer_norm.bias"), gb.data(), sv.data(), cvv.data());
-            x.cqeb = st.put_f32(cvv.data(), Hd);
-            x.cqes = st.put_f32(sv.data(), Hd);
-            std::fill(acc.begin(), acc.end(), 0.0);   // reused as [d][H d]
-            for (size_t n = 0; n < d; n++)
-                for (size_t h = 0; h < H; h++)
-                    for (size_t t = 0; t < HD; t++) {
-                        const double a = (double)Wo[n * d + h * HD + t];
-                        const float* wv = Wv + (h * HD + t) * d;
-                        double* row = acc.data() + n * Hd + h * d;
-                        for (size_t j = 0; j < d; j++) row[j] += a * (double)wv[j];
-                    }
-            for (size_t n = 0; n < d * Hd; n++) Wvo[n] = (float)acc[n];
-            for (size_t n = 0; n < d; n++) {
-                double a = (double)bo[n];
-                for (size_t r = 0; r < d; r++) a += (double)Wo[n * d + r] * (double)bv[r];
-                ob[n] = (float)a;
-            }
-            x.coe = st.put_mat(Wvo.data(), d, Hd, Hd);
-            x.coeb = st.put_f32(ob.data(), d);
+                for (size_t j = 0; j < d; j++)
+                    for (size_t t = 0; t < HD; t++) wkT[(h * d + j) * HD + t] = Wk[(h * HD + t) * d + j];
+            o_cqx[i] = st.put_mat(wkT.data(), H * d, HD, HD);
         }
     }
     size_t o_ckvb = st.put_f32(ckvb.data(), ckvb.size());
@@ -904,9 +861,9 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     }
     if (cross_es)
         for (int i = 0; i < c.dec_layers; i++) {
-            const DecEs& x = des[i];
-            m->dec[i].cqe_w = P(x.cqe); m->dec[i].cqe_b = PF(x.cqeb); m->dec[i].cqe_s = PF(x.cqes);
-            m->dec[i].coe_w = P(x.coe); m->dec[i].coe_b = PF(x.coeb);
+            m->dec[i].cqx_w = P(o_cqx[i]);
+            m->dec[i].cv_w = (char*)P(o_ckv) + ((size_t)i * 2 + 1) * d * d * m->esz;
+            m->dec[i].cv_b = PF(o_ckvb) + ((size_t)i * 2 + 1) * d;
         }
     m->cross_es = cross_es;
     m->cross_kv_w = P(o_ckv); m->cross_kv_b = PF(o_ckvb);
