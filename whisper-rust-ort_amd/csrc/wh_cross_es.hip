@@ -56,7 +56,8 @@ constexpr int ES_D = 512, ES_H = 8, ES_TK = 32, ES_NSTAGE = 4;
 constexpr int ES_ROWB = ES_D * 2;                      // bytes per key row
 constexpr int ES_TILEB = ES_TK * ES_ROWB;              // 32 KiB
 constexpr int ES_SCP = 36;                             // floats per (dim half, head) row of the score exchange (32 keys + pad)
-constexpr int ES_LDS = ES_NSTAGE * ES_TILEB + 2 * 2 * ES_H * ES_SCP * 4 + ES_H * ES_D * 4;   // ring + score exchange + next queries = 148.5 KiB
+constexpr int ES_SCB = 4 * ES_H * ES_SCP;             // floats per score-exchange buffer: [dim half][hi | lo of the query][head][ES_SCP]
+constexpr int ES_LDS = ES_NSTAGE * ES_TILEB + 2 * ES_SCB * 4 + ES_H * ES_D * 4;   // ring + score exchange + next queries = 153 KiB
 
 template <int N> __device__ __forceinline__ void es_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -65,9 +66,13 @@ __device__ __forceinline__ void es_glds16(const void* src, char* lds_wave_base) 
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, AUX);
 }
 
-__device__ __forceinline__ float es_sum32(float v) {   // v(lane) + v(lane ^ 32), in every lane
+__device__ __forceinline__ float es_sum32(float v) {   // v(lane) + v(lane ^ 32), in every lane (tools/cross_es2_proto.hip.txt)
     const wh_u32x2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(t.x) + __uint_as_float(t.y);
+}
+
+__device__ __forceinline__ float es_ror8(float v) {    // v of lane ^ 8 (same 16-lane row): DPP row_ror:8
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
 }
 
 // qe : [B][8][512] f32 expanded queries (natural-log score units)        E: [B][S][512] bf16 encoder states (final LayerNorm applied)
@@ -91,8 +96,8 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es(const fl
     constexpr int NSTAGE = ES_NSTAGE, LA = NSTAGE - 1;   // LA tiles staged ahead of the one being consumed
     static_assert(NSTAGE == 4 && (NL == 1 || NL == 2), "ring of four 32-key slots; one or two loader waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sc = reinterpret_cast<float*>(smem + NSTAGE * ES_TILEB);   // [2 tiles][2 dim halves][8 heads][ES_SCP]
-    float* Qs = sc + 2 * 2 * ES_H * ES_SCP;                               // [8][512] f32: the next clip's expanded queries
+    float* sc = reinterpret_cast<float*>(smem + NSTAGE * ES_TILEB);   // [2 tiles][ES_SCB]
+    float* Qs = sc + 2 * ES_SCB;                               // [8][512] f32: the next clip's expanded queries
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntile = (S + ES_TK - 1) / ES_TK;
@@ -208,15 +213,11 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es(const fl
             d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[s], ef[s], d0, 0, 0, 0);
             d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[s + 1], ef[s + 1], d1, 0, 0, 0);
         }
-        // rows 0-7 (lane groups 0, 1) carry hi(qe), rows 8-15 (groups 2, 3) lo(qe): add lane and lane ^ 32
-        float v[4];
+        // rows 0-7 (lane groups 0, 1) carry hi(qe), rows 8-15 (groups 2, 3) lo(qe): both go to the exchange buffer as they are (the
+        // readers add the four partials of a score: two dim halves x {hi, lo}) — cheaper than adding lane and lane ^ 32 here
+        float* dst = sc + buf * ES_SCB + ((hf * 2 + (fg >> 1)) * ES_H + 4 * (fg & 1)) * ES_SCP + 16 * kt + fl;
 #pragma unroll
-        for (int i = 0; i < 4; i++) v[i] = es_sum32(d0[i] + d1[i]);
-        if (fg < 2) {
-            float* dst = sc + buf * (2 * ES_H * ES_SCP) + (hf * ES_H + 4 * fg) * ES_SCP + 16 * kt + fl;
-#pragma unroll
-            for (int i = 0; i < 4; i++) dst[i * ES_SCP] = v[i];
-        }
+        for (int i = 0; i < 4; i++) dst[i * ES_SCP] = d0[i] + d1[i];
     };
 
     f32x4 acc[8];   // rows 4 fg + i: heads 4 fg + i in lane groups 0 and 1 (the P operand's rows 8-15 are zero)
@@ -253,11 +254,11 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es(const fl
         const char* tb = smem + slot * ES_TILEB;
         // ---- every LDS read of this iteration up front, in the order of use (LDS returns in order, so each consumer waits only
         // for what it needs): scores of tile g (softmax), score operands of tile g + 1, the 8 x 8 blocks of tile g (output)
-        const int h = fl & 7;
-        const float* s0 = sc + (g & 1) * (2 * ES_H * ES_SCP) + h * ES_SCP + kb;
-        const float* s1 = s0 + ES_H * ES_SCP;
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(s0), a1 = *reinterpret_cast<const f32x4*>(s0 + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(s1), b1 = *reinterpret_cast<const f32x4*>(s1 + 4);
+        // lanes fl and fl + 8 share a head (the operand's rows 8-15 are zero): each takes four of the lane group's eight keys
+        const int h = fl & 7, kq = kb + 4 * (fl >> 3);
+        const float* s0 = sc + (g & 1) * ES_SCB + h * ES_SCP + kq;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(s0), a1 = *reinterpret_cast<const f32x4*>(s0 + ES_H * ES_SCP);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(s0 + 2 * ES_H * ES_SCP), b1 = *reinterpret_cast<const f32x4*>(s0 + 3 * ES_H * ES_SCP);
         bf16x8 ef[8];
         if (more) score_reads(nslot, ef);
         wh_u32x4 blk[8];
@@ -274,31 +275,41 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es(const fl
         // ---- online softmax of tile g: lane -> head fl & 7, keys kb .. kb + 7 of the tile (identical in the four waves)
         bf16x8 pa;
         {
-            float sv[8];
+            float sv[4];
             float tmax = -INFINITY;
-            const int key0 = t * ES_TK + kb;
+            const int key0 = t * ES_TK + kq;
 #pragma unroll
-            for (int u = 0; u < 8; u++) sv[u] = (u < 4) ? a0[u & 3] + b0[u & 3] : a1[u & 3] + b1[u & 3];
+            for (int u = 0; u < 4; u++) sv[u] = (a0[u] + a1[u]) + (b0[u] + b1[u]);
             if (t == ntile - 1) {   // (wave-uniform) keys past the end of the clip
 #pragma unroll
-                for (int u = 0; u < 8; u++) sv[u] = (key0 + u < S) ? sv[u] : -INFINITY;
+                for (int u = 0; u < 4; u++) sv[u] = (key0 + u < S) ? sv[u] : -INFINITY;
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) tmax = fmaxf(tmax, sv[u]);
-            tmax = xrow_max(tmax);   // over the four lane groups: all 32 keys of the tile
+            for (int u = 0; u < 4; u++) tmax = fmaxf(tmax, sv[u]);
+            tmax = fmaxf(tmax, es_ror8(tmax));   // the head's other four keys of this lane group
+            tmax = xrow_max(tmax);               // over the four lane groups: all 32 keys of the tile
             const float m_new = fmaxf(m_run, tmax);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
             float ps = 0.0f;
-            float pv[8];
+            float pv[4];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 4; u++) {
                 pv[u] = __builtin_amdgcn_exp2f(sv[u] - m_new);   // masked key: exp2(-inf) = 0
                 ps += pv[u];
             }
-            // rows 0-7 carry bf16(p); rows 8-15 stay zero (a remainder row would be lost in the bf16 rounding of the output anyway)
-            const bool hi = fl < 8;
-#pragma unroll
-            for (int u = 0; u < 8; u++) pa[u] = (bf16)(hi ? pv[u] : 0.0f);
+            // rows 0-7 carry bf16(p) of keys kb .. kb + 7: this lane's four and, through DPP, its partner's; rows 8-15 stay zero (a
+            // remainder row would be lost in the bf16 rounding of the output anyway)
+            {
+                const bf16x2 p01 = {(bf16)pv[0], (bf16)pv[1]}, p23 = {(bf16)pv[2], (bf16)pv[3]};
+                unsigned own0, own1;
+                __builtin_memcpy(&own0, &p01, 4);
+                __builtin_memcpy(&own1, &p23, 4);
+                const unsigned oth0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own0, 0x128, 0xF, 0xF, true);   // row_ror:8 = lane fl ^ 8 of the row
+                const unsigned oth1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own1, 0x128, 0xF, 0xF, true);
+                const bool hi = fl < 8;
+                const wh_u32x4 pw = {hi ? own0 : 0u, hi ? own1 : 0u, hi ? oth0 : 0u, hi ? oth1 : 0u};
+                __builtin_memcpy(&pa, &pw, 16);
+            }
             l_run = l_run * alpha + ps;
             m_run = m_new;
             // the accumulators hold rows 4 fg + i = heads 4 fg + i (fg < 2); head h's factor sits in lane h: through SGPRs (v_readlane),
@@ -341,7 +352,8 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es(const fl
         if (++t < ntile) continue;
         // ---- the clip ends: normalise and store (rows 0-7 = lane groups 0 and 1)
         {
-            const float inv = 1.0f / xrow_sum(l_run);
+            const float lh = l_run + es_ror8(l_run);   // the head's two key quartets
+            const float inv = 1.0f / xrow_sum(lh);
             float ih[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) ih[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv), q));
