@@ -268,7 +268,9 @@ def main() -> None:
     if wb.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: libwhisper_hip has no CPU fallback")
     if a.clips <= 0:   # the largest device batch whose workspace + caches fit comfortably
-        a.clips = {"base": 1024, "large-v3": 256}.get(a.preset, 256)
+        # whisper-base: 2048 = the library's largest context (WH_MAX_BATCH); with the cross-attention on the encoder states a clip
+        # holds 1.5 MB instead of 18.4 MB of decode-side state, and the latency-bound decode GEMMs amortise further
+        a.clips = {"base": 2048, "large-v3": 256}.get(a.preset, 256)
         if prec == wb.WH_PREC_F32 and a.preset in ("base", "large-v3"):
             a.clips //= 4
     if a.pipeline is None:
@@ -369,42 +371,6 @@ def main() -> None:
     run_step(prefetch=False)
     breakdown = {k: {"ms": sum(cx.profile_get()[k]["ms"] for cx in ctxs) / a.streams,
                      "launches": sum(cx.profile_get()[k]["launches"] for cx in ctxs)} for k in wb.KG_NAMES}
-    # BASELINE configs[1] (batch = 1 clip on one GPU): per-clip end-to-end latency, untimed extra
-    b1_ms = []
-    if rank == 0 and not a.no_batch1:
-        ctx1 = wb.Context(model, 1)
-        for i in range(6):
-            t1 = time.perf_counter()
-            ctx1.transcribe_batch_device(d_pcm + (i % a.clips) * 480000 * 4, 1, params)
-            if i:
-                b1_ms.append((time.perf_counter() - t1) * 1e3)
-        ctx1.close()
-    # BASELINE configs[2] at its own 8-GPU shard size (512 clips / 8 = 64 per GPU) as ONE 64-clip batch: untimed extra
-    b64 = None
-    if rank == 0 and not a.no_batch1 and a.clips >= 64 and a.clips != 64:
-        ctx64 = wb.Context(model, 64)
-        t64 = []
-        for i in range(4):
-            t1 = time.perf_counter()
-            ctx64.transcribe_batch_device(d_pcm, 64, params)
-            if i:
-                t64.append((time.perf_counter() - t1) * 1e3)
-        ctx64.close()
-        b64 = {"ms_per_batch": float(np.median(t64)), "rtfx": 64 * 30e3 / float(np.median(t64)),
-               "note": "BASELINE configs[2]'s 8-GPU shard (64 clips) as one batch on one GPU; p95 per clip = the batch time"}
-    # the 256-clip device batch rounds 1 and 2 quoted as the headline, for round-to-round comparison: untimed extra
-    b256 = None
-    if rank == 0 and not a.no_batch1 and a.clips > 256:
-        ctx256 = wb.Context(model, 256)
-        t256 = []
-        for i in range(4):
-            t1 = time.perf_counter()
-            ctx256.transcribe_batch_device(d_pcm, 256, params)
-            if i:
-                t256.append((time.perf_counter() - t1) * 1e3)
-        ctx256.close()
-        b256 = {"ms_per_batch": float(np.median(t256)), "rtfx": 256 * 30e3 / float(np.median(t256)),
-                "note": "one 256-clip device batch per call (the per-step workload of the round-1/2 lines)"}
     # timed region: only the dominant kernel (decoder cross-attention) is bracketed by HIP events
     for cx in ctxs:
         if a.graph_timed:
@@ -456,6 +422,57 @@ def main() -> None:
         assert n_results == world * a.clips
     else:
         n_results = len(toks)
+    # (the untimed side measurements below run AFTER the timed region: run before it, their ~10 s of extra GPU work left the chip at a
+    # lower clock for the timed steps — the issue-bound dominant kernel then read 265 instead of 250 us per launch)
+    # BASELINE configs[1] (batch = 1 clip on one GPU): per-clip end-to-end latency, untimed extra
+    b1_ms = []
+    if rank == 0 and not a.no_batch1:
+        ctx1 = wb.Context(model, 1)
+        for i in range(6):
+            t1 = time.perf_counter()
+            ctx1.transcribe_batch_device(d_pcm + (i % a.clips) * 480000 * 4, 1, params)
+            if i:
+                b1_ms.append((time.perf_counter() - t1) * 1e3)
+        ctx1.close()
+    # BASELINE configs[2] at its own 8-GPU shard size (512 clips / 8 = 64 per GPU) as ONE 64-clip batch: untimed extra
+    b64 = None
+    if rank == 0 and not a.no_batch1 and a.clips >= 64 and a.clips != 64:
+        ctx64 = wb.Context(model, 64)
+        t64 = []
+        for i in range(4):
+            t1 = time.perf_counter()
+            ctx64.transcribe_batch_device(d_pcm, 64, params)
+            if i:
+                t64.append((time.perf_counter() - t1) * 1e3)
+        ctx64.close()
+        b64 = {"ms_per_batch": float(np.median(t64)), "rtfx": 64 * 30e3 / float(np.median(t64)),
+               "note": "BASELINE configs[2]'s 8-GPU shard (64 clips) as one batch on one GPU; p95 per clip = the batch time"}
+    # the 256-clip device batch rounds 1 and 2 quoted as the headline, for round-to-round comparison: untimed extra
+    b256 = None
+    if rank == 0 and not a.no_batch1 and a.clips > 256:
+        ctx256 = wb.Context(model, 256)
+        t256 = []
+        for i in range(4):
+            t1 = time.perf_counter()
+            ctx256.transcribe_batch_device(d_pcm, 256, params)
+            if i:
+                t256.append((time.perf_counter() - t1) * 1e3)
+        ctx256.close()
+        b256 = {"ms_per_batch": float(np.median(t256)), "rtfx": 256 * 30e3 / float(np.median(t256)),
+                "note": "one 256-clip device batch per call (the per-step workload of the round-1/2 lines)"}
+    # ... and the 1024-clip device batch of the round-2 / round-3 lines
+    b1024 = None
+    if rank == 0 and not a.no_batch1 and a.clips > 1024:
+        ctx1024 = wb.Context(model, 1024)
+        t1024 = []
+        for i in range(3):
+            t1 = time.perf_counter()
+            ctx1024.transcribe_batch_device(d_pcm, 1024, params)
+            if i:
+                t1024.append((time.perf_counter() - t1) * 1e3)
+        ctx1024.close()
+        b1024 = {"ms_per_batch": float(np.median(t1024)), "rtfx": 1024 * 30e3 / float(np.median(t1024)),
+                 "note": "one 1024-clip device batch per call (the per-step workload of the round-2 / round-3 lines)"}
 
     if rank == 0:
         cross_es = ctxs[0].cross_mode == 1
@@ -538,8 +555,8 @@ def main() -> None:
                        "pipeline": ({"enc_cus": a.enc_cus or "all", "dec_cus": a.dec_cus or "all",
                                      "note": "step i's token loop and step i+1's log-mel + encoder run side by side on disjoint compute units; "
                                              "every timed step executes one encoder pass and one decode pass"} if a.pipeline else None),
-                       "cross_attention": ("on the encoder states (k_dec_cross_attn_es: S x d bf16 per clip, layer and token; K / V projections folded into "
-                                           "the decode GEMMs around it)" if cross_es else "on the projected K / V cache (2 S x d per clip, layer and token)"),
+                       "cross_attention": ("on the encoder states (k_dec_cross_attn_es: S x d bf16 per clip, layer and token; the K projection as a query-side expansion kernel, the V "
+                                           "projection as a grouped decode GEMM behind it)" if cross_es else "on the projected K / V cache (2 S x d per clip, layer and token)"),
                        "gather": backend, "results_gathered": n_results, "row_check": row_check},
             "rtf": elapsed / audio_s,   # reference definition: latency / duration (src/main.rs:1191)
             "clips_per_s": a.clips * a.steps * world / elapsed,
@@ -549,6 +566,7 @@ def main() -> None:
                        if b1_ms else None),
             "batch64": b64,
             "batch256": b256,
+            "batch1024": b1024,
             "stage_ms_per_step": {k: v / a.steps * 1e3 for k, v in stage.items()},
             "kernel_group_ms_per_step": {k: round(v["ms"], 3) for k, v in breakdown.items()},
             "kernel_group_launches": {k: v["launches"] for k, v in breakdown.items()},

@@ -122,7 +122,7 @@ int wh_model_precision(const wh_model* m);
 int wh_model_export_tensor(const wh_model* m, const char* name, float* out, size_t cap, size_t* n_out);
 
 /* ---- per-stream context: workspace + KV cache for up to max_batch clips in flight ------------- */
-#define WH_MAX_BATCH 1024   /* largest max_batch wh_ctx_create accepts */
+#define WH_MAX_BATCH 2048   /* largest max_batch wh_ctx_create accepts */
 int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out);
 /* Chip partition (no reference counterpart; the reference overlaps windows on CPU threads, src/main.rs:884-919).
  * A context created with these options runs log-mel + encoder on one HIP stream and the cross-K/V projection + token

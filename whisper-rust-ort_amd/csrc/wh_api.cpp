@@ -750,7 +750,7 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     *out = nullptr;
     if (opts->struct_size != sizeof(wh_ctx_opts)) { wh_set_error("wh_ctx_create_ex: wh_ctx_opts.struct_size does not match this library"); return WH_ERR_ARG; }
     const int max_batch = opts->max_batch;
-    if (max_batch < 1 || max_batch > WH_MAX_BATCH) { wh_set_error("max_batch must be 1..1024"); return WH_ERR_ARG; }
+    if (max_batch < 1 || max_batch > WH_MAX_BATCH) { wh_set_error("max_batch must be 1..2048"); return WH_ERR_ARG; }
     if ((opts->enc_cu_mask_words && !opts->enc_cu_mask) || (opts->dec_cu_mask_words && !opts->dec_cu_mask)) {
         wh_set_error("wh_ctx_create_ex: NULL CU mask with a non-zero word count");
         return WH_ERR_ARG;
