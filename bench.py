@@ -422,11 +422,12 @@ def main() -> None:
         assert n_results == world * a.clips
     else:
         n_results = len(toks)
-    # (the untimed side measurements below run AFTER the timed region: run before it, their ~10 s of extra GPU work left the chip at a
+    # (the untimed side measurements below — one GPU only: with more ranks the others would sit in the process group's teardown meanwhile —
+    # run AFTER the timed region: run before it, their ~10 s of extra GPU work left the chip at a
     # lower clock for the timed steps — the issue-bound dominant kernel then read 265 instead of 250 us per launch)
     # BASELINE configs[1] (batch = 1 clip on one GPU): per-clip end-to-end latency, untimed extra
     b1_ms = []
-    if rank == 0 and not a.no_batch1:
+    if rank == 0 and world == 1 and not a.no_batch1:
         ctx1 = wb.Context(model, 1)
         for i in range(6):
             t1 = time.perf_counter()
@@ -436,7 +437,7 @@ def main() -> None:
         ctx1.close()
     # BASELINE configs[2] at its own 8-GPU shard size (512 clips / 8 = 64 per GPU) as ONE 64-clip batch: untimed extra
     b64 = None
-    if rank == 0 and not a.no_batch1 and a.clips >= 64 and a.clips != 64:
+    if rank == 0 and world == 1 and not a.no_batch1 and a.clips >= 64 and a.clips != 64:
         ctx64 = wb.Context(model, 64)
         t64 = []
         for i in range(4):
@@ -449,7 +450,7 @@ def main() -> None:
                "note": "BASELINE configs[2]'s 8-GPU shard (64 clips) as one batch on one GPU; p95 per clip = the batch time"}
     # the 256-clip device batch rounds 1 and 2 quoted as the headline, for round-to-round comparison: untimed extra
     b256 = None
-    if rank == 0 and not a.no_batch1 and a.clips > 256:
+    if rank == 0 and world == 1 and not a.no_batch1 and a.clips > 256:
         ctx256 = wb.Context(model, 256)
         t256 = []
         for i in range(4):
@@ -462,7 +463,7 @@ def main() -> None:
                 "note": "one 256-clip device batch per call (the per-step workload of the round-1/2 lines)"}
     # ... and the 1024-clip device batch of the round-2 / round-3 lines
     b1024 = None
-    if rank == 0 and not a.no_batch1 and a.clips > 1024:
+    if rank == 0 and world == 1 and not a.no_batch1 and a.clips > 1024:
         ctx1024 = wb.Context(model, 1024)
         t1024 = []
         for i in range(3):
