@@ -438,8 +438,8 @@ def test_base_bf16_256_vs_64_clip_context_logit_bound(gpu, golden_dir, big):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("nb", [64, 256, 1024, 2048])
 def test_f32_base_batched_contexts_match_golden(gpu, golden_dir, nb):
-    """whisper-base dims, exact-f32 mode, 64-, 256- and 1024-clip contexts (cross_splits 4 / 1, merged vs direct attention
-    output, non-temporal K/V loads from 256 up, the row-group variants of the decode GEMMs and the LM head; 1024 = the
+    """whisper-base dims, exact-f32 mode, 64-, 256-, 1024- and 2048-clip contexts (cross_splits 4 / 1, merged vs direct attention
+    output, non-temporal K/V loads from 256 up, the row-group variants of the decode GEMMs and the LM head; 2048 = the
     library's largest batch and bench.py's per-step workload): golden clips 0 and
     3 sit at several batch rows among filler clips.  Tokens identical to the golden free-running streams, top-k logits
     within 1e-3 — the same bar as the one-clip path."""
