@@ -423,8 +423,8 @@ def main() -> None:
     else:
         n_results = len(toks)
     # (the untimed side measurements below — one GPU only: with more ranks the others would sit in the process group's teardown meanwhile —
-    # run AFTER the timed region: run before it, their ~10 s of extra GPU work left the chip at a
-    # lower clock for the timed steps — the issue-bound dominant kernel then read 265 instead of 250 us per launch)
+    # run AFTER the timed region: run before it, the issue-bound dominant kernel read 265 instead of 250 us per launch in the
+    # timed steps)
     # BASELINE configs[1] (batch = 1 clip on one GPU): per-clip end-to-end latency, untimed extra
     b1_ms = []
     if rank == 0 and world == 1 and not a.no_batch1:
