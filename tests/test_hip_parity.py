@@ -665,3 +665,24 @@ def test_cross_es_matches_projected_kv_and_golden(gpu, golden_dir, nb):
     srt = np.sort(out["kv"], axis=2)
     decided = (srt[:, :, -1] - srt[:, :, -2]) > 2.0 * d[:, None]
     assert (out["es"].argmax(axis=2)[decided] == out["kv"].argmax(axis=2)[decided]).all()
+
+
+def test_cross_es_longform_equals_staged_calls(gpu):
+    """Long-form entry and the staged calls (whisper_log_mel -> run_encoder -> greedy_decode_with_past) on a context whose token
+    loop attends over the encoder states: the windows of a 72.5 s file decoded together must give, token for token, what each window
+    gives alone on the same context (same kernels, results independent of the batch; reference loop src/main.rs:870-915)."""
+    model = wb.Model("synthetic:base:1234", 0, wb.WH_PREC_BF16)
+    ctx = wb.Context(model, 4, cross_es=True)
+    assert ctx.cross_mode == 1
+    prompt, eot = small_prompt(ms.PRESETS["base"])
+    pcm = np.concatenate([ms.synth_clip(40), ms.synth_clip(41), ms.synth_clip(42)[:200000]])  # 72.5 s
+    params = wb.DecodeParams(prompt, 12, eot, [eot])
+    got = ctx.transcribe_longform(pcm, params)
+    offs = wb.longform_plan(pcm.size)
+    assert len(got) == len(offs) == 3
+    mel_full = ctx.whisper_log_mel(pcm)                 # whole-file mel, global max (:870-872)
+    for off, toks in zip(offs, got):
+        ctx.run_encoder(orc.window_mel(mel_full, off // 160, 3000), want_output=False)
+        alone, _ = ctx.greedy_decode_with_past(params)
+        assert toks.tolist() == alone.tolist()
+    ctx.close()
