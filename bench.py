@@ -423,7 +423,7 @@ def main() -> None:
     else:
         n_results = len(toks)
     # (the untimed side measurements below — one GPU only: with more ranks the others would sit in the process group's teardown meanwhile —
-    # run AFTER the timed region: run before it, the issue-bound dominant kernel read 265 instead of 250 us per launch in the
+    # run AFTER the timed region: run before it, the dominant kernel read 265 instead of 250 us per launch in the
     # timed steps)
     # BASELINE configs[1] (batch = 1 clip on one GPU): per-clip end-to-end latency, untimed extra
     b1_ms = []

@@ -37,9 +37,11 @@
 // No cross-wave merge at the end of a clip: every wave has seen every key and owns its own 128 output dims.
 //
 // Measured (MI355X, 1024 clips per launch, inside bench.py's step): 250 us = 6.3 TB/s = 0.79 of the HBM roof; the ring alone
-// (no arithmetic) streams at 6.7 TB/s = 236 us.  The difference is instruction issue of the four computing waves (one per SIMD,
-// ~1,850 cycles per tile at the ~1.4 GHz the chip holds under this load against ~1,650 for the stream): records in DESIGN.md
-// section 5d and tools/cross_es2_proto.hip.txt (a form with the softmax shared through LDS: three barriers per 64 keys, no faster).
+// (no arithmetic) streams at 6.7 TB/s = 236 us.  The difference is not the computing waves' instruction issue (~1,630 cycles per tile
+// against ~1,650 for the stream at the ~1.4 GHz the chip holds here): a form with a quarter of that work moved to a sixth wave
+// (tools/cross_es_smw.patch.txt) runs no faster; the LDS-DMA pieces land more slowly while the computing waves read LDS, and the ring
+// cannot keep more of them in flight.  Records: DESIGN.md section 5d, tools/cross_es2_proto.hip.txt (64-key steps, softmax shared through
+// LDS with three barriers per step: no faster either).
 #include <stdlib.h>
 
 #include <algorithm>
