@@ -336,7 +336,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
         // no projection: the token loop attends over the encoder states themselves (wh_cross_es.hip).  Their final LayerNorm runs
         // here, on the decode stream, into decode-side storage — the encoder-side workspace is free for the next pass afterwards
         Prof pr(c, WH_KG_DEC_GEMM);
-        wh_launch_layernorm(s, prec, c->x, m->enc_ln_w, m->enc_ln_b, c->es_E, (long)nb * S, (int)d);
+        wh_launch_layernorm_blocks(s, prec, c->x, m->enc_ln_w, m->enc_ln_b, c->es_E, (long)nb * S, (int)d, c->es_rows == (int)S ? 0 : (int)S, c->es_rows);
     } else {
         Prof pr(c, WH_KG_DEC_GEMM);
         GemmArgs g;
@@ -423,7 +423,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 }
                 {
                     Prof pr(c, WH_KG_DEC_CROSS_ATTN);
-                    wh_launch_dec_cross_attn_es(s, c->dqe, c->es_E, c->dctx, (int)S, nb, mpad, kv_nt);
+                    wh_launch_dec_cross_attn_es(s, c->dqe, c->es_E, c->dctx, (int)S, c->es_rows, nb, mpad, kv_nt);
                 }
                 {   // per head: W_v,h ctx_h + b_v,h → the attention output the out-projection below expects (slab layout)
                     Prof pr(c, WH_KG_DEC_GEMM);
@@ -812,7 +812,12 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
         wh_set_error("wh_ctx_create_ex: WH_CTX_CROSS_ES_ON needs a bf16 model of whisper-base geometry (d_model 512, 8 heads)");
         return WH_ERR_UNSUPPORTED;
     }
-    const size_t o_ckv = cv.take(c->cross_es ? B * S * d * esz : Ld * 2 * B * S * d * esz);
+    // rows from one clip's encoder states to the next: 20 rows (20 KiB) of padding, so that the lock-step streams of the persistent
+    // workgroups (clip i, i + 256, ...) do not all sit on the same 4 KiB phase of the 1,536,000-byte clip pitch: 491 -> 480-485 us per
+    // 2048-clip launch (tools/es_state_probe.py, WH_ES_PAD = 0 / 12 / 20 / 28 / 44 / 84: 491 / 487 / 482 / 484 / 485 / 490)
+    c->es_rows = (int)S + 20;
+    if (const char* e = getenv("WH_ES_PAD")) c->es_rows = (int)S + std::max(0, atoi(e));   // (A/B runs)
+    const size_t o_ckv = cv.take(c->cross_es ? B * (size_t)c->es_rows * d * esz : Ld * 2 * B * S * d * esz);
     const bool f8 = m->prec == WH_PREC_FP8;
     const size_t o_ckv8 = f8 ? cv.take(Ld * 2 * B * S * d) : 0, o_kvam = f8 ? cv.take(Ld * 2 * B * H * 4) : 0;
     // fp8-MFMA encoder (wh_gemm8_mx.hip): MX activations when every contraction length is one the kernel takes

@@ -94,7 +94,7 @@ __device__ __forceinline__ float es_ror8(float v) {    // v of lane ^ 8 (same 16
 // own.  Tile g + 1 must therefore have landed at the top of iteration g: NSTAGE - 2 tiles stay in flight.
 template <int AUX, int NL, int ABL = 0>   // ABL (tools/es_bench.hip only): 1 = ring, waits and barriers only; 2 = phase stamps (s_memtime) of workgroup 0 into dbg
 __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es(const float* __restrict__ qe, const bf16* __restrict__ E,
-                                                                         bf16* __restrict__ out, int S, int mpad, int B, unsigned long long* dbg) {
+                                                                         bf16* __restrict__ out, int S, int e_rows, int mpad, int B, unsigned long long* dbg) {
     constexpr int NSTAGE = ES_NSTAGE, LA = NSTAGE - 1;   // LA tiles staged ahead of the one being consumed
     static_assert(NSTAGE == 4 && (NL == 1 || NL == 2), "ring of four 32-key slots; one or two loader waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es(const fl
         int st_clip = blockIdx.x, st_t = 0, st_slot = 0;   // tiles are staged strictly in sequence
         auto stage_next = [&]() {
             char* base = smem + st_slot * ES_TILEB;
-            const char* Et = reinterpret_cast<const char*>(E) + ((long)st_clip * S + (long)st_t * ES_TK) * ES_ROWB;   // wave-uniform
+            const char* Et = reinterpret_cast<const char*>(E) + ((long)st_clip * e_rows + (long)st_t * ES_TK) * ES_ROWB;   // wave-uniform
             if (st_t * ES_TK + ES_TK <= S) {
 #pragma unroll
                 for (int j = 0; j < PPT; j++) es_glds16<AUX>(Et + voff[j], base + (lw * PPT + j) * ES_ROWB);
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es(const fl
                 for (int j = 0; j < PPT; j++) {
                     const int r = lw * PPT + j;
                     const int key = min(st_t * ES_TK + r, S - 1);
-                    es_glds16<AUX>(reinterpret_cast<const char*>(E) + ((long)st_clip * S + key) * ES_ROWB + ((lane ^ (r & 15)) << 4), base + r * ES_ROWB);
+                    es_glds16<AUX>(reinterpret_cast<const char*>(E) + ((long)st_clip * e_rows + key) * ES_ROWB + ((lane ^ (r & 15)) << 4), base + r * ES_ROWB);
                 }
             }
             st_slot = st_slot + 1 == NSTAGE ? 0 : st_slot + 1;
@@ -435,7 +435,7 @@ unsigned long long* wh_es_bench_dbg = nullptr;
 
 bool wh_cross_es_geometry(int d, int n_heads, int S) { return d == ES_D && n_heads == ES_H && S >= 4 * ES_TK; }
 
-void wh_launch_dec_cross_attn_es(hipStream_t s, const float* qe, const void* E, void* out, int S, int B, int mpad, bool stream_nt) {
+void wh_launch_dec_cross_attn_es(hipStream_t s, const float* qe, const void* E, void* out, int S, int e_rows, int B, int mpad, bool stream_nt) {
     static const int nt_env = [] { const char* e = getenv("WH_CROSS_NT"); return e ? atoi(e) : -1; }();
     static const int nl = [] { const char* e = getenv("WH_ES_LOADERS"); return e ? atoi(e) : 1; }();        // (A/B runs) loader waves per workgroup
     static const int persist = [] { const char* e = getenv("WH_ES_PERSIST"); return e ? atoi(e) : 1; }();   // (A/B runs) 0: one workgroup per clip
@@ -449,7 +449,7 @@ void wh_launch_dec_cross_attn_es(hipStream_t s, const float* qe, const void* E, 
 #define WH_ES_LAUNCH(AUX_, NL_, ...)                                                                                                \
     do {                                                                                                                            \
         wh_ensure_dyn_lds((const void*)k_dec_cross_attn_es<AUX_, NL_, ##__VA_ARGS__>, ES_LDS);                                      \
-        hipLaunchKernelGGL((k_dec_cross_attn_es<AUX_, NL_, ##__VA_ARGS__>), dim3(grid), dim3(256 + 64 * NL_), ES_LDS, s, qe, (const bf16*)E, (bf16*)out, S, mpad, B, es_dbg); \
+        hipLaunchKernelGGL((k_dec_cross_attn_es<AUX_, NL_, ##__VA_ARGS__>), dim3(grid), dim3(256 + 64 * NL_), ES_LDS, s, qe, (const bf16*)E, (bf16*)out, S, e_rows, mpad, B, es_dbg); \
     } while (0)
 #ifdef WH_ES_BENCH
     if (const char* e = getenv("WH_ES_ABL")) { if (atoi(e) == 2) WH_ES_LAUNCH(2, 1, 2); else WH_ES_LAUNCH(2, 1, 1); return; }

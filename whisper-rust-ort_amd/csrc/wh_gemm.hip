@@ -197,10 +197,15 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 }
 
 // ---- LayerNorm over rows of length d (f32 in, T out); one wave per row -------------------------
+// output row of input row `row`: contiguous, or — in_blk > 0 — blocks of in_blk rows (a clip's states) placed out_blk rows apart
+__device__ __forceinline__ long ln_out_row(long row, int in_blk, int out_blk) {
+    return in_blk > 0 ? (row / in_blk) * out_blk + row % in_blk : row;
+}
+
 // [3P] torch LayerNorm eps 1e-5, biased variance (modeling_whisper.py:371,377,642,790).
 template <typename TO>
 __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ w,
-                                                   const float* __restrict__ b, TO* __restrict__ y, long rows, int d) {
+                                                   const float* __restrict__ b, TO* __restrict__ y, long rows, int d, int in_blk, int out_blk) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
         for (int e = 0; e < 4; e++) { float t = tv[e] - mean; q += t * t; }
     }
     const float rstd = rsqrtf(dpp_wave_sum(q) / (float)d + 1e-5f);
-    TO* yr = y + row * d;
+    TO* yr = y + ln_out_row(row, in_blk, out_blk) * d;
 #pragma unroll
     for (int i = 0; i < MAXV; i++) {
         if (i < nv) {
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
 // once, so four loads per lane are in flight instead of two.
 template <int SWEEPS>
 __global__ __launch_bounds__(256) void k_layernorm_w8(const float* __restrict__ x, const float* __restrict__ w,
-                                                      const float* __restrict__ b, bf16* __restrict__ y, long rows, int d) {
+                                                      const float* __restrict__ b, bf16* __restrict__ y, long rows, int d, int in_blk, int out_blk) {
     const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
     if (row0 >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(256) void k_layernorm_w8(const float* __restrict__ 
                 o[e] = (bf16)((v[r][i][0][e] - mean[r]) * rstd[r] * w0[e] + b0[e]);
                 o[4 + e] = (bf16)((v[r][i][1][e] - mean[r]) * rstd[r] * w1[e] + b1[e]);
             }
-            *reinterpret_cast<bf16x8*>(y + (row0 + r) * d + c) = o;
+            *reinterpret_cast<bf16x8*>(y + ln_out_row(row0 + r, in_blk, out_blk) * d + c) = o;
         }
     }
 }
@@ -347,15 +352,19 @@ void wh_launch_gemm(hipStream_t s, int prec, bool out_f32, const GemmArgs& g) {
     }
 }
 
-void wh_launch_layernorm(hipStream_t s, int prec, const float* x, const float* w, const float* b, void* y, long rows,
-                         int d) {
+void wh_launch_layernorm_blocks(hipStream_t s, int prec, const float* x, const float* w, const float* b, void* y, long rows, int d, int in_blk,
+                                int out_blk) {
     dim3 grid((unsigned)((rows + 3) / 4));
     if (prec != WH_PREC_F32 && (d == 512 || d == 1024) && getenv("WH_LN_W8_OFF") == nullptr) {
         dim3 g8((unsigned)((rows + 7) / 8));
-        if (d == 512) hipLaunchKernelGGL(k_layernorm_w8<1>, g8, dim3(256), 0, s, x, w, b, (bf16*)y, rows, d);
-        else hipLaunchKernelGGL(k_layernorm_w8<2>, g8, dim3(256), 0, s, x, w, b, (bf16*)y, rows, d);
+        if (d == 512) hipLaunchKernelGGL(k_layernorm_w8<1>, g8, dim3(256), 0, s, x, w, b, (bf16*)y, rows, d, in_blk, out_blk);
+        else hipLaunchKernelGGL(k_layernorm_w8<2>, g8, dim3(256), 0, s, x, w, b, (bf16*)y, rows, d, in_blk, out_blk);
         return;
     }
-    if (prec == WH_PREC_F32) hipLaunchKernelGGL(k_layernorm<float>, grid, dim3(256), 0, s, x, w, b, (float*)y, rows, d);
-    else hipLaunchKernelGGL(k_layernorm<bf16>, grid, dim3(256), 0, s, x, w, b, (bf16*)y, rows, d);
+    if (prec == WH_PREC_F32) hipLaunchKernelGGL(k_layernorm<float>, grid, dim3(256), 0, s, x, w, b, (float*)y, rows, d, in_blk, out_blk);
+    else hipLaunchKernelGGL(k_layernorm<bf16>, grid, dim3(256), 0, s, x, w, b, (bf16*)y, rows, d, in_blk, out_blk);
+}
+
+void wh_launch_layernorm(hipStream_t s, int prec, const float* x, const float* w, const float* b, void* y, long rows, int d) {
+    wh_launch_layernorm_blocks(s, prec, x, w, b, y, rows, d, 0, 0);
 }

@@ -148,6 +148,7 @@ struct wh_ctx {
     // then not allocated); dqe [B][H d] f32 expanded queries; dctx = the H d context values per clip, slab layout
     bool cross_es = false;
     void* es_E = nullptr;
+    int es_rows = 0;            // rows from one clip's states to the next in es_E (>= n_audio_ctx)
     float* dq32 = nullptr;      // [B][d] f32 cross-attention queries (pre-scaled)
     float* dqe = nullptr;
     void* dctx = nullptr;

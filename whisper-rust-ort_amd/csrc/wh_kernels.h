@@ -150,6 +150,9 @@ void wh_launch_gemm8_mx(hipStream_t s, int out, const GemmArgs& g);
 void wh_launch_layernorm_mx(hipStream_t s, const float* x, const float* w, const float* b, void* codes, void* exps, long rows, int d);
 void wh_launch_layernorm(hipStream_t s, int prec, const float* x, const float* w, const float* b, void* y, long rows,
                          int d);
+// the same with the output in blocks: input rows [i * in_blk, (i + 1) * in_blk) go to output rows i * out_blk ...  (in_blk == 0: contiguous)
+void wh_launch_layernorm_blocks(hipStream_t s, int prec, const float* x, const float* w, const float* b, void* y, long rows, int d, int in_blk,
+                                int out_blk);
 void wh_launch_enc_attn(hipStream_t s, int prec, const void* qk, const void* vT, void* out, int n_clips, int S, int d,
                         int n_heads, int ldv);
 
@@ -177,7 +180,7 @@ bool wh_cross_es_geometry(int d, int n_heads, int S);
 // expanded queries qe[m][h][j] = sum_t q[m][64 h + t] * wkT[h][j][t]: q [M][d] f32 (pre-scaled, bias included), wkT [H][d][64] bf16
 // (head h's rows of W_k, transposed), qe [M][H][d] f32.  q enters the bf16 MFMAs as hi + lo, so nothing of it is rounded.
 void wh_launch_dec_qexpand(hipStream_t s, const float* q, const void* wkT, float* qe, int M, int d, int n_heads);
-void wh_launch_dec_cross_attn_es(hipStream_t s, const float* qe, const void* E, void* out, int S, int B, int mpad, bool stream_nt);
+void wh_launch_dec_cross_attn_es(hipStream_t s, const float* qe, const void* E, void* out, int S, int e_rows, int B, int mpad, bool stream_nt);   // e_rows >= S: rows between two clips' states
 
 // dynamic LDS to request for a cross-attention launch of total_wgs workgroups whose kernel needs own_bytes: caps the resident
 // workgroups per CU at two for large launches (wh_decode.hip)
