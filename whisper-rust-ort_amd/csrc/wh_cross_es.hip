@@ -77,7 +77,8 @@ __device__ __forceinline__ float es_ror8(float v) {    // v of lane ^ 8 (same 16
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
 }
 
-// qe : [B][8][512] f32 expanded queries (natural-log score units)        E: [B][S][512] bf16 encoder states (final LayerNorm applied)
+// qe : [B][8][512] f32 expanded queries (natural-log score units)        E: [B][e_rows][512] bf16 encoder states (final LayerNorm applied),
+// e_rows >= S: the clips' states sit e_rows rows apart (20 rows of padding take the lock-step streams off a common 4 KiB phase, wh_api.cpp)
 // out: ctx as the decode GEMM's operand, slab layout [8 * 512 / 32][mpad][32] bf16, column h * 512 + dim
 //
 // Roles.  Waves 0-3 compute; waves 4 .. 3 + NL only load: every LDS-DMA piece of the ring and of the query prefetch is issued by
