@@ -59,6 +59,13 @@ extern "C" {
                           Convolutions, LayerNorm parameters, biases, embeddings (so the tied LM head) and the remaining
                           activations as in WH_PREC_BF16.  Reference analogue: ORT dynamic quantisation of MatMul/Gemm
                           (int8 weights, per-call quantised activations), quantize_onnx_int8.py:37-42 */
+#define WH_PREC_F16X3 3 /* f32 results on the fp16 matrix cores: every operand of a contraction is the sum of two fp16
+                          limbs (x = hi + lo, 22 significant bits), every product three v_mfma_f32_16x16x32_f16
+                          (hi.hi + hi.lo + lo.hi, f32 accumulate); everything outside the contractions (residual stream,
+                          LayerNorm, softmax, GELU, argmax) in f32 exactly as WH_PREC_F32.  Meets the reference's f32
+                          results (src/main.rs:777: f32 logits from f32 ORT graphs) — tokens identical, logits within
+                          1e-3 — at matrix-core speed.  Operands must lie within fp16 range (|x| < 65504),
+                          as in any fp16 Whisper deployment. */
 
 #define WH_N_FRAMES 3000      /* mel frames per 30 s window (src/main.rs:896) */
 #define WH_CLIP_SAMPLES 480000 /* 30 s @ 16 kHz */

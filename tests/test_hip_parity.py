@@ -2,7 +2,8 @@
 committed golden vectors.  Run with `-m gpu` on an MI355X.
 
 Tolerances
-  F32 mode (exact-f32 MFMA): mel 1e-4, encoder 1e-3, logits 1e-3 (north_star), tokens exact.
+  F32 mode (exact-f32 MFMA) and F16X3 mode (two fp16 limbs per operand, three fp16 MFMAs per product: the in-tolerance mode
+  at matrix-core speed): mel 1e-4, encoder 1e-3, logits 1e-3 (north_star), tokens exact — the same tests, parametrised.
   BF16 mode: reported as error statistics; tokens must match wherever the oracle's top-1 margin
   exceeds the measured logit error bound (teacher-forced), see test_bf16_*.
 """
@@ -18,6 +19,7 @@ from whisper_rust_ort_amd import modelspec as ms
 pytestmark = pytest.mark.gpu
 
 MEL_TOL, ENC_TOL, LOGIT_TOL = 1e-4, 1e-3, 1e-3
+EXACT_MODES = ["f32", "f16x3"]   # the two precisions held to north_star's bar (tokens identical, logits within 1e-3)
 
 
 @pytest.fixture(scope="module")
@@ -103,9 +105,10 @@ def test_empty_audio_is_rejected(gpu):
 # ------------------------------------------------------------------------------------------------
 # encoder + decode, exact-f32 mode, against the oracle
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec_name", EXACT_MODES)
 @pytest.mark.parametrize("preset,seed,clip", [("nano", 7, 0), ("micro", 11, 2)])
-def test_f32_full_path_matches_oracle(gpu, preset, seed, clip):
-    b = bundle(preset, seed, wb.WH_PREC_F32)
+def test_f32_full_path_matches_oracle(gpu, preset, seed, clip, prec_name):
+    b = bundle(preset, seed, wb.PRECISIONS[prec_name])
     dims = b.dims
     pcm = ms.synth_clip(clip)
     mel = b.ctx.whisper_log_mel(pcm)
@@ -137,10 +140,11 @@ def test_f32_full_path_matches_oracle(gpu, preset, seed, clip):
     np.testing.assert_allclose(lc, rlc, rtol=0, atol=LOGIT_TOL)
 
 
-def test_f32_matches_golden_vectors(gpu, golden_dir):
+@pytest.mark.parametrize("prec_name", EXACT_MODES)
+def test_f32_matches_golden_vectors(gpu, golden_dir, prec_name):
     for name in ("nano_s7_c1.npz", "micro_s11_c2.npz"):
         g = np.load(os.path.join(golden_dir, name))
-        b = bundle(str(g["preset"]), int(g["seed"]), wb.WH_PREC_F32)
+        b = bundle(str(g["preset"]), int(g["seed"]), wb.PRECISIONS[prec_name])
         pcm = ms.synth_clip(int(g["clip"]))
         mel = b.ctx.whisper_log_mel(pcm)
         np.testing.assert_allclose(mel[:, ::25], g["mel_slice"], rtol=0, atol=MEL_TOL)
@@ -161,10 +165,11 @@ def test_f32_matches_golden_vectors(gpu, golden_dir):
             np.testing.assert_allclose(lc[i][g["top_ids_c"][i]], g["top_vals_c"][i], rtol=0, atol=LOGIT_TOL)
 
 
-def test_f32_whisper_base_matches_golden(gpu, golden_dir):
+@pytest.mark.parametrize("prec_name", EXACT_MODES)
+def test_f32_whisper_base_matches_golden(gpu, golden_dir, prec_name):
     """whisper-base dims, hash-seeded weights: token-for-token + logits within 1e-3 (configs[1])."""
     g = np.load(os.path.join(golden_dir, "base_s1234_c0.npz"))
-    b = bundle("base", 1234, wb.WH_PREC_F32)
+    b = bundle("base", 1234, wb.PRECISIONS[prec_name])
     pcm = ms.synth_clip(0)
     mel = b.ctx.whisper_log_mel(pcm)
     np.testing.assert_allclose(mel[:, ::25], g["mel_slice"], rtol=0, atol=MEL_TOL)
@@ -184,6 +189,8 @@ def test_f32_whisper_base_matches_golden(gpu, golden_dir):
     for i in range(len(lc)):
         np.testing.assert_allclose(lc[i][g["top_ids_c"][i]], g["top_vals_c"][i], rtol=0, atol=LOGIT_TOL)
     np.testing.assert_allclose(lc[:4, :2048], g["logits_c_head"], rtol=0, atol=LOGIT_TOL)
+    worst = max(float(np.abs(la[i][g["top_ids_a"][i]] - g["top_vals_a"][i]).max()) for i in range(len(la)))
+    print(f"{prec_name} base, one clip: max |logit - golden| over 128 free-running rows {worst:.2e}; encoder max |d| {np.abs(enc[g['enc_rows']] - g['enc_slice']).max():.2e}")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -436,15 +443,16 @@ def test_base_bf16_256_vs_64_clip_context_logit_bound(gpu, golden_dir, big):
 # ------------------------------------------------------------------------------------------------
 # the batched kernel variants bench.py times, against the f32 golden vectors (HF-pinned)
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec_name", EXACT_MODES)
 @pytest.mark.parametrize("nb", [64, 256, 1024, 2048])
-def test_f32_base_batched_contexts_match_golden(gpu, golden_dir, nb):
-    """whisper-base dims, exact-f32 mode, 64-, 256-, 1024- and 2048-clip contexts (cross_splits 4 / 1, merged vs direct attention
+def test_f32_base_batched_contexts_match_golden(gpu, golden_dir, nb, prec_name):
+    """whisper-base dims, exact-f32 mode and the split-fp16 mode, 64-, 256-, 1024- and 2048-clip contexts (cross_splits 4 / 1, merged vs direct attention
     output, non-temporal K/V loads from 256 up, the row-group variants of the decode GEMMs and the LM head; 2048 = the
     library's largest batch and bench.py's per-step workload): golden clips 0 and
     3 sit at several batch rows among filler clips.  Tokens identical to the golden free-running streams, top-k logits
     within 1e-3 — the same bar as the one-clip path."""
     g = {0: np.load(os.path.join(golden_dir, "base_s1234_c0.npz")), 3: np.load(os.path.join(golden_dir, "base_s1234_c3.npz"))}
-    b = bundle("base", 1234, wb.WH_PREC_F32, max_batch=nb)
+    b = bundle("base", 1234, wb.PRECISIONS[prec_name], max_batch=nb)
     prompt, eot = g[0]["prompt"].tolist(), int(g[0]["eot"])
     rows = {0: 0, 1: 3, 17: 0, nb // 2: 3, nb - 2: 3, nb - 1: 0}
     pcm = {0: ms.synth_clip(0), 3: ms.synth_clip(3)}
@@ -482,7 +490,7 @@ def test_f32_base_batched_contexts_match_golden(gpu, golden_dir, nb):
             for i in range(len(lc[r])):
                 worst = max(worst, float(np.abs(lc[r][i][g[c]["top_ids_c"][i]] - g[c]["top_vals_c"][i]).max()))
             np.testing.assert_allclose(lc[r][:4, :2048], g[c]["logits_c_head"], rtol=0, atol=LOGIT_TOL)
-    print(f"f32 base, {nb}-clip context: max |logit - golden| over all compared rows {worst:.2e}")
+    print(f"{prec_name} base, {nb}-clip context: max |logit - golden| over all compared rows {worst:.2e}")
     assert worst <= LOGIT_TOL
 
 

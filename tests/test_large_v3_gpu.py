@@ -13,14 +13,15 @@ from whisper_rust_ort_amd import modelspec as ms
 pytestmark = pytest.mark.gpu
 
 
-def test_large_v3_f32_against_golden(golden_dir):
-    """BASELINE configs[3] geometry in the exact-f32 mode against the committed golden vectors
+@pytest.mark.parametrize("prec_name", ["f32", "f16x3"])
+def test_large_v3_f32_against_golden(golden_dir, prec_name):
+    """BASELINE configs[3] geometry in the exact-f32 mode and in the split-fp16 mode (WH_PREC_F16X3) against the committed golden vectors
     (tests/golden/large-v3_s5_c7.npz, generated in the build container by make_golden.py from the HF Whisper classes with
     the same hash-seeded weights): log-mel, encoder slices, greedy tokens, per-step top-k logits, teacher-forced logits.
     No CPU oracle run is needed on the GPU box."""
     g = np.load(os.path.join(golden_dir, "large-v3_s5_c7.npz"))
     dims = ms.PRESETS["large-v3"]
-    model = wb.Model(f"synthetic:large-v3:{int(g['seed'])}", 0, wb.WH_PREC_F32)   # the C++ generator (bit-identical to numpy's)
+    model = wb.Model(f"synthetic:large-v3:{int(g['seed'])}", 0, wb.PRECISIONS[prec_name])   # the C++ generator (bit-identical to numpy's)
     ctx = wb.Context(model, 1)
     pcm = ms.synth_clip(int(g["clip"]))
     mel = ctx.whisper_log_mel(pcm)
@@ -45,7 +46,7 @@ def test_large_v3_f32_against_golden(golden_dir):
     for i in range(len(lc)):
         worst = max(worst, float(np.abs(lc[i][g["top_ids_c"][i]] - g["top_vals_c"][i]).max()))
     np.testing.assert_allclose(lc[:4, :2048], g["logits_c_head"], rtol=0, atol=1e-3)
-    print(f"large-v3 f32 vs golden: encoder max abs err {enc_err:.2e}, logits max abs err {worst:.2e}")
+    print(f"large-v3 {prec_name} vs golden: encoder max abs err {enc_err:.2e}, logits max abs err {worst:.2e}")
     assert worst <= 1e-3
 
 

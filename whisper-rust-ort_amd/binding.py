@@ -20,8 +20,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libwhisper_hip.so")
 
-WH_PREC_F32, WH_PREC_BF16, WH_PREC_FP8 = 0, 1, 2
-PRECISIONS = {"f32": WH_PREC_F32, "bf16": WH_PREC_BF16, "fp8": WH_PREC_FP8}
+WH_PREC_F32, WH_PREC_BF16, WH_PREC_FP8, WH_PREC_F16X3 = 0, 1, 2, 3
+PRECISIONS = {"f32": WH_PREC_F32, "bf16": WH_PREC_BF16, "fp8": WH_PREC_FP8, "f16x3": WH_PREC_F16X3}
 WH_N_FRAMES, WH_CLIP_SAMPLES = 3000, 480000
 KG_NAMES = ("mel", "enc_gemm", "enc_attn", "dec_cross_attn", "dec_gemm", "dec_other")
 

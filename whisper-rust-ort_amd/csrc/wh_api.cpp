@@ -49,6 +49,13 @@ int fail(wh_ctx* c, int code, const char* fmt, ...) {
                         __LINE__, #expr);                                                         \
     } while (0)
 
+// a kernel launcher that reports a launch it cannot run (GEMM geometry / mode checks): surface it as this call's error
+#define CTX_LAUNCH(c, expr)                                                                       \
+    do {                                                                                          \
+        const int _rc = (expr);                                                                   \
+        if (_rc != WH_OK) return fail(c, _rc, "%s", wh_global_error().c_str());                   \
+    } while (0)
+
 // ---- profiling scope: brackets the launches of one kernel group with events -------------------
 struct Prof {
     wh_ctx* c;
@@ -126,7 +133,7 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
         g.C = (char*)c->h1 + d * esz; g.ldc = d; g.c_bs = (long)H1_ROWS * d;
         g.bias = m->conv1_b; g.bias_mode = 1; g.act = 1;
         g.M = nb * WH_N_FRAMES; g.N = (int)d; g.K = m->conv1_k;
-        wh_launch_gemm(s, prec, false, g);
+        CTX_LAUNCH(c, wh_launch_gemm(s, prec, false, g));
     }
     const long rows = (long)nb * S;
     // LayerNorm fold (bf16, c->enc_fold): every GEMM that produces the residual stream also writes it as bf16 plus per-row
@@ -153,7 +160,7 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
         g.R = m->enc_pos; g.ldr = d; g.r_bs = 0;
         g.M = nb * (int)S; g.N = (int)d; g.K = (int)(3 * d);
         producer(g);
-        wh_launch_gemm(s, prec, true, g);
+        CTX_LAUNCH(c, wh_launch_gemm(s, prec, true, g));
         finish_stats();
     }
     for (int l = 0; l < D.enc_layers; l++) {
@@ -163,7 +170,7 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
         const bool mx = c->mx_ok;
         if (!fold) {
             Prof p(c, WH_KG_ENC_GEMM);
-            if (mx) wh_launch_layernorm_mx(s, c->x, L.ln1_w, L.ln1_b, c->xn8, c->xn8_sc, rows, (int)d);
+            if (mx) CTX_LAUNCH(c, wh_launch_layernorm_mx(s, c->x, L.ln1_w, L.ln1_b, c->xn8, c->xn8_sc, rows, (int)d));
             else wh_launch_layernorm(s, prec, c->x, L.ln1_w, L.ln1_b, c->xn, rows, (int)d);
         }
         {   // Q|K projection (q pre-scaled, k has no bias)
@@ -173,8 +180,8 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
             g.A = c->xn; g.lda = d; g.W = L.qk_w; g.ldw = d; g.C = c->qk; g.ldc = 2 * d;
             g.bias = L.qk_b; g.bias_mode = 1; g.wscale = L.qk_sc; g.M = (int)rows; g.N = (int)(2 * d); g.K = (int)d;
             if (fold) { g.A = c->xb; g.W = L.qk_wf; g.bias = L.qk_c; g.ln_mode = 1; g.ln_stat = c->enc_stat; g.ln_s = L.qk_s; }
-            if (mx) { g.A = c->xn8; g.a_sc = c->xn8_sc; g.W = L.qk_w8; wh_launch_gemm8_mx(s, 0, g); }
-            else wh_launch_gemm(s, prec, false, g);
+            if (mx) { g.A = c->xn8; g.a_sc = c->xn8_sc; g.W = L.qk_w8; CTX_LAUNCH(c, wh_launch_gemm8_mx(s, 0, g)); }
+            else CTX_LAUNCH(c, wh_launch_gemm(s, prec, false, g));
         }
         {   // V^T[e][key] = W_v x^T + b_v: per-clip product with the weight as the row operand
             Prof p(c, WH_KG_ENC_GEMM);
@@ -187,9 +194,9 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
             if (fold) {   // the LayerNorm statistics belong to the COLUMNS here (keys), s and c to the rows (features)
                 g.A = L.v_wf; g.W = c->xb; g.bias = L.v_c; g.ln_mode = 2; g.ln_stat = c->enc_stat; g.ln_stat_zs = 2 * S; g.ln_s = L.v_s;
             }
-            if (mx && d >= 256) { g.A = L.v_w8; g.W = c->xn8; g.w_sc8 = c->xn8_sc; g.w_sc_zs = S * 4 * wh_mx_nkp((int)d); wh_launch_gemm8_mx(s, 0, g); }
+            if (mx && d >= 256) { g.A = L.v_w8; g.W = c->xn8; g.w_sc8 = c->xn8_sc; g.w_sc_zs = S * 4 * wh_mx_nkp((int)d); CTX_LAUNCH(c, wh_launch_gemm8_mx(s, 0, g)); }
             else if (mx) return fail(c, WH_ERR_UNSUPPORTED, "MX activations need d_model >= 256");
-            else wh_launch_gemm(s, prec, false, g);
+            else CTX_LAUNCH(c, wh_launch_gemm(s, prec, false, g));
         }
         {
             Prof p(c, WH_KG_ENC_ATTN);
@@ -202,12 +209,12 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
             g.A = c->att; g.lda = d; g.W = L.o_w; g.ldw = d; g.C = c->x; g.ldc = d;
             g.bias = L.o_b; g.bias_mode = 1; g.wscale = L.o_sc; g.R = c->x; g.ldr = d; g.M = (int)rows; g.N = (int)d; g.K = (int)d;
             producer(g);
-            wh_launch_gemm(s, prec, true, g);
+            CTX_LAUNCH(c, wh_launch_gemm(s, prec, true, g));
             finish_stats();
         }
         if (!fold) {
             Prof p(c, WH_KG_ENC_GEMM);
-            if (mx) wh_launch_layernorm_mx(s, c->x, L.ln2_w, L.ln2_b, c->xn8, c->xn8_sc, rows, (int)d);
+            if (mx) CTX_LAUNCH(c, wh_launch_layernorm_mx(s, c->x, L.ln2_w, L.ln2_b, c->xn8, c->xn8_sc, rows, (int)d));
             else wh_launch_layernorm(s, prec, c->x, L.ln2_w, L.ln2_b, c->xn, rows, (int)d);
         }
         {   // fc1 + GELU (MX: the output leaves as e4m3 codes + block exponents, fc2's operand)
@@ -217,8 +224,8 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
             g.A = c->xn; g.lda = d; g.W = L.fc1_w; g.ldw = d; g.C = c->hbuf; g.ldc = F;
             g.bias = L.fc1_b; g.bias_mode = 1; g.wscale = L.fc1_sc; g.act = 1; g.M = (int)rows; g.N = (int)F; g.K = (int)d;
             if (fold) { g.A = c->xb; g.W = L.fc1_wf; g.bias = L.fc1_c; g.ln_mode = 1; g.ln_stat = c->enc_stat; g.ln_s = L.fc1_s; }
-            if (mx) { g.A = c->xn8; g.a_sc = c->xn8_sc; g.W = L.fc1_w8; g.C = c->h8; g.c_sc = c->h8_sc; wh_launch_gemm8_mx(s, 2, g); }
-            else wh_launch_gemm(s, prec, false, g);
+            if (mx) { g.A = c->xn8; g.a_sc = c->xn8_sc; g.W = L.fc1_w8; g.C = c->h8; g.c_sc = c->h8_sc; CTX_LAUNCH(c, wh_launch_gemm8_mx(s, 2, g)); }
+            else CTX_LAUNCH(c, wh_launch_gemm(s, prec, false, g));
         }
         {
             Prof p(c, WH_KG_ENC_GEMM);
@@ -226,18 +233,18 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
             g.small_ctx = c->max_batch <= WH_SMALL_CTX_CLIPS;
             g.A = c->hbuf; g.lda = F; g.W = L.fc2_w; g.ldw = F; g.C = c->x; g.ldc = d;
             g.bias = L.fc2_b; g.bias_mode = 1; g.wscale = L.fc2_sc; g.R = c->x; g.ldr = d; g.M = (int)rows; g.N = (int)d; g.K = (int)F;
-            if (mx) { g.A = c->h8; g.a_sc = c->h8_sc; g.W = L.fc2_w8; wh_launch_gemm8_mx(s, 1, g); }
-            else { producer(g); wh_launch_gemm(s, prec, true, g); finish_stats(); }
+            if (mx) { g.A = c->h8; g.a_sc = c->h8_sc; g.W = L.fc2_w8; CTX_LAUNCH(c, wh_launch_gemm8_mx(s, 1, g)); }
+            else { producer(g); CTX_LAUNCH(c, wh_launch_gemm(s, prec, true, g)); finish_stats(); }
         }
     }
     {
         Prof p(c, WH_KG_ENC_GEMM);
         // the cross K/V projection's operand: MX form when that GEMM runs on the fp8 matrix cores, else the compute dtype
         // (fold: the final LayerNorm lives in the cross K/V projection's weights; its statistics are in c->enc_stat already)
-        if (c->mx_ok) wh_launch_layernorm_mx(s, c->x, m->enc_ln_w, m->enc_ln_b, c->xn8, c->xn8_sc, rows, (int)d);
+        if (c->mx_ok) CTX_LAUNCH(c, wh_launch_layernorm_mx(s, c->x, m->enc_ln_w, m->enc_ln_b, c->xn8, c->xn8_sc, rows, (int)d));
         else if (!fold) wh_launch_layernorm(s, prec, c->x, m->enc_ln_w, m->enc_ln_b, c->enc_out, rows, (int)d);
         if (want_f32) {
-            if (prec == WH_PREC_F32) hipMemcpyAsync(c->enc_out_f32, c->enc_out, rows * d * 4, hipMemcpyDeviceToDevice, s);
+            if (esz == 4) hipMemcpyAsync(c->enc_out_f32, c->enc_out, rows * d * 4, hipMemcpyDeviceToDevice, s);
             else wh_launch_layernorm(s, WH_PREC_F32, c->x, m->enc_ln_w, m->enc_ln_b, c->enc_out_f32, rows, (int)d);
         }
     }
@@ -348,8 +355,8 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
         if (c->enc_fold) {   // encoder's final LayerNorm folded in: raw bf16 rows, statistics from the last fc2's epilogue
             g.A = c->xb; g.W = m->cross_kv_wf; g.bias = m->cross_kv_c; g.ln_mode = 1; g.ln_stat = c->enc_stat; g.ln_s = m->cross_kv_s;
         }
-        if (c->mx_ok) { g.A = c->xn8; g.a_sc = c->xn8_sc; g.W = m->cross_kv_w8; wh_launch_gemm8_mx(s, 0, g); }   // xn8 = MX(final LN), run_encoder
-        else wh_launch_gemm(s, prec, false, g);
+        if (c->mx_ok) { g.A = c->xn8; g.a_sc = c->xn8_sc; g.W = m->cross_kv_w8; CTX_LAUNCH(c, wh_launch_gemm8_mx(s, 0, g)); }   // xn8 = MX(final LN), run_encoder
+        else CTX_LAUNCH(c, wh_launch_gemm(s, prec, false, g));
         if (f8) {  // bf16 projection → e4m3 codes, one scale per (layer, K|V, clip, head)
             const long planes = (long)D.dec_layers * 2 * nb;
             CTX_HIP(c, hipMemsetAsync(c->kv_amax, 0, planes * D.n_heads * 4, s));
@@ -605,7 +612,7 @@ int run_mel_batch(wh_ctx* c, const float* pcm, int nb) {
     }
     {
         Prof p(c, WH_KG_MEL);
-        if (m->prec == WH_PREC_F32)
+        if (m->esz == 4)
             wh_launch_mel_tokens<float>(s, c->raw, (long)m->dims.n_mels * RAW_LD, RAW_LD, nullptr, nullptr, c->d_nframes,
                                         c->d_gmax, 0, m->dims.n_mels, nb, (float*)c->melT, (long)TOK_ROWS * m->dims.n_mels);
         else
@@ -824,13 +831,17 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     // (decided from the model and the context only, never from a call's clip count: S >= 256 rows is one full tile even for one clip)
     // contraction lengths: any multiple of 128 from 256 on (whisper-large-v3: 1280, 5120); d_model must be a width k_layernorm_mx exists for
     auto mx_k = [](size_t k) { return k >= 256 && (k % 128) == 0; };
-    c->mx_ok = f8 && mx_k(d) && mx_k(F) && wh_mx_ln_width((int)d) && S >= 256 && getenv("WH_NO_MX") == nullptr;
+    // (the same predicates wh_gemm8_mx_applicable applies to every shape of the path: Q|K / fc1 / fc2 / cross-K/V rows = clips x S >= one tile,
+    // the per-clip V^T product with M = d_model rows and N = S columns in groups of four)
+    c->mx_ok = f8 && mx_k(d) && mx_k(F) && wh_mx_ln_width((int)d) && S >= 256 && (S % 4) == 0 && getenv("WH_NO_MX") == nullptr;
     const size_t o_xn8 = c->mx_ok ? cv.take(B * S * d) : 0, o_xn8s = c->mx_ok ? cv.take(B * S * 4 * wh_mx_nkp((int)d)) : 0;
     const size_t o_h8 = c->mx_ok ? cv.take(B * S * F) : 0, o_h8s = c->mx_ok ? cv.take(B * S * 4 * wh_mx_nkp((int)F)) : 0;
     // WH_PREC_BF16 on the LDS-DMA GEMM (contexts beyond a few clips, widths it has tiles for): the encoder's LayerNorms are
     // folded into their consumer GEMMs — decided from the model and the context, never from a call's clip count
-    c->enc_fold = m->prec == WH_PREC_BF16 && max_batch > WH_SMALL_CTX_CLIPS && d >= 256 && (d % 64) == 0 && (F % 64) == 0 && S >= 256 &&
-                  m->cross_kv_wf != nullptr && getenv("WH_NO_ENC_FOLD") == nullptr;
+    // (every folded GEMM must pass wh_gemm8_applicable: rows = clips x S >= 256, V^T with M = d_model >= 256 and N = S % 4 == 0, producers
+    // with N = d_model % 64 == 0; WH_GEMM8=0 sends every GEMM to k_gemm, which has no fold — then the LayerNorm kernels run)
+    c->enc_fold = m->prec == WH_PREC_BF16 && max_batch > WH_SMALL_CTX_CLIPS && d >= 256 && (d % 64) == 0 && (F % 64) == 0 && S >= 256 && (S % 4) == 0 &&
+                  m->cross_kv_wf != nullptr && wh_gemm8_enabled() && getenv("WH_NO_ENC_FOLD") == nullptr;
     const size_t o_xb = c->enc_fold ? cv.take(B * S * d * 2) : 0, o_epart = c->enc_fold ? cv.take((d / 64) * B * S * 2 * 4) : 0;
     const size_t o_estat = c->enc_fold ? cv.take(B * S * 2 * 4) : 0;
     const size_t o_sk = cv.take(Ld * B * H * TC * WH_HEAD_DIM * esz), o_sv = cv.take(Ld * B * H * TC * WH_HEAD_DIM * esz);
@@ -1027,7 +1038,7 @@ int wh_encode(wh_ctx* c, const float* mel, float* enc_out) {
     CTX_HIP(c, hipMemcpyAsync(c->d_nframes, &nf, 4, hipMemcpyHostToDevice, s));
     CTX_HIP(c, hipStreamSynchronize(s));
     CTX_HIP(c, hipEventRecord(c->ev[1], s));
-    if (c->m->prec == WH_PREC_F32)
+    if (c->m->esz == 4)
         wh_launch_mel_tokens<float>(s, c->mel_stage, 0, WH_N_FRAMES, nullptr, nullptr, c->d_nframes, nullptr, 1, D.n_mels, 1,
                                     (float*)c->melT, (long)TOK_ROWS * D.n_mels);
     else
@@ -1257,7 +1268,7 @@ int wh_transcribe_longform(wh_ctx* c, const float* pcm, size_t n_samples, double
         CTX_HIP(c, hipMemcpyAsync(c->d_nframes, nfs.data(), 4, hipMemcpyHostToDevice, s));
         CTX_HIP(c, hipStreamSynchronize(s));
         CTX_HIP(c, hipEventRecord(c->ev[4], s));
-        if (c->m->prec == WH_PREC_F32)
+        if (c->m->esz == 4)
             wh_launch_mel_tokens<float>(s, c->raw_long, 0, (long)ld, c->d_src_index, c->d_frame_start, c->d_nframes, c->d_gmax, 0,
                                         D.n_mels, nb, (float*)c->melT, (long)TOK_ROWS * D.n_mels);
         else

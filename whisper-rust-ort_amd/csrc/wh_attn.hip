@@ -28,6 +28,7 @@ namespace {
 template <typename T> struct HalfFrag;  // 4 consecutive elements
 template <> struct HalfFrag<bf16> { typedef bf16x4 type; };
 template <> struct HalfFrag<float> { typedef f32x4 type; };
+template <> struct HalfFrag<xf32> { typedef f32x4 type; };
 
 __device__ __forceinline__ bf16x8 join_half(bf16x4 a, bf16x4 b) { return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 __device__ __forceinline__ f32x8 join_half(f32x4 a, f32x4 b) { return f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
@@ -35,6 +36,14 @@ __device__ __forceinline__ void pack_p(bf16x8& f, const f32x4& a, const f32x4& b
     f = bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
 }
 __device__ __forceinline__ void pack_p(f32x8& f, const f32x4& a, const f32x4& b) { f = f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+// WH_PREC_F16X3: the probabilities enter the second product as two fp16 limbs like any other operand
+__device__ __forceinline__ void pack_p(xfrag& f, const f32x4& a, const f32x4& b) { f = x3_split(f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}); }
+template <typename T> struct Joiner {
+    template <typename H> static __device__ __forceinline__ auto join(H a, H b) { return join_half(a, b); }
+};
+template <> struct Joiner<xf32> {
+    static __device__ __forceinline__ xfrag join(f32x4 a, f32x4 b) { return x3_split(join_half(a, b)); }
+};
 
 template <typename T, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void k_enc_attn(const T* __restrict__ qk, const T* __restrict__ vT,
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_enc_attn(const T* __restrict__ 
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 const T* vp = &Vc[(te * 16 + fl) * LDV + 32 * ks + 4 * fg];
-                const frag_t vf = join_half(*reinterpret_cast<const half_t*>(vp), *reinterpret_cast<const half_t*>(vp + 16));
+                const frag_t vf = Joiner<T>::join(*reinterpret_cast<const half_t*>(vp), *reinterpret_cast<const half_t*>(vp + 16));
                 mma16(o[0][te], vf, pf[0][ks]);
                 mma16(o[1][te], vf, pf[1][ks]);
             }
@@ -245,6 +254,11 @@ void wh_launch_enc_attn(hipStream_t s, int prec, const void* qk, const void* vT,
         const size_t sm = (size_t)2 * 2 * 64 * (64 + 4) * 4;  // 69.6 KB: above the default dynamic-LDS limit
         wh_ensure_dyn_lds((const void*)k_enc_attn<float, 4>, sm);
         hipLaunchKernelGGL((k_enc_attn<float, 4>), grid, dim3(256), sm, s, (const float*)qk, (const float*)vT, (float*)out, S, d, ldv, n_heads);
+    } else if (prec == WH_PREC_F16X3) {   // f32 tiles, fp16 limbs at the fragment loads
+        dim3 grid(((S + 127) / 128) * n_heads * n_clips);
+        const size_t sm = (size_t)2 * 2 * 64 * (64 + 4) * 4;
+        wh_ensure_dyn_lds((const void*)k_enc_attn<xf32, 4>, sm);
+        hipLaunchKernelGGL((k_enc_attn<xf32, 4>), grid, dim3(256), sm, s, (const xf32*)qk, (const xf32*)vT, (xf32*)out, S, d, ldv, n_heads);
     } else {
         const size_t sm = (size_t)2 * 2 * 64 * (64 + 8) * 2;
         // 8 waves = 256 query rows per workgroup: each K / V^T tile is staged once per 256 queries instead of once per 128

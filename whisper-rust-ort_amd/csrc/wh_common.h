@@ -44,14 +44,48 @@ __device__ __forceinline__ void mma16(f32x4& acc, const f32x8& a, const f32x8& b
     for (int e = 0; e < 8; e++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// WH_PREC_F16X3: f32 storage, contractions on the fp16 matrix cores.  An operand value x is carried as two fp16 limbs,
+// hi = f16(x), lo = f16(x - hi) (x - hi is exact in f32; 11 + 11 significant bits), and a product is three MFMAs:
+//   sum_k a_k b_k  ~=  sum a.lo b.hi + sum a.hi b.lo + sum a.hi b.hi      (the lo.lo term, 2^-22 relative, is dropped)
+// accumulated in f32 — measured against exact f32 on whisper-base: max |d logit| 6e-5, the distance between two f32
+// implementations being 3e-5 (tools/x3_numerics.py; with bf16 limbs the same scheme measures 4e-4).
+// `xf32` is the element-type tag of such an operand in memory (the bytes of a float); its fragment holds the limbs, so a
+// fragment is split once when it is loaded and reused by every MFMA it feeds.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+struct xf32 { float v; };
+struct xfrag { f16x8 hi, lo; };
+template <> struct FragT<xf32> { typedef xfrag type; };
+__device__ __forceinline__ xfrag x3_split(const f32x8& x) {
+    xfrag r;
+    r.hi = __builtin_convertvector(x, f16x8);                    // 4 x v_cvt_pk_f16_f32 (RNE)
+    r.lo = __builtin_convertvector(x - __builtin_convertvector(r.hi, f32x8), f16x8);
+    return r;
+}
+template <>
+__device__ __forceinline__ xfrag load_frag<xf32>(const xf32* p) {
+    return x3_split(*reinterpret_cast<const f32x8*>(p));
+}
+__device__ __forceinline__ void mma16(f32x4& acc, const xfrag& a, const xfrag& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.lo, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, acc, 0, 0, 0);
+}
+
 template <typename T> __device__ __forceinline__ T cvt_out(float v);
+template <> __device__ __forceinline__ xf32 cvt_out<xf32>(float v) { return xf32{v}; }
 template <> __device__ __forceinline__ float cvt_out<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 cvt_out<bf16>(float v) { return (bf16)v; }  // v_cvt_pk_bf16_f32: RNE, NaN-safe
 
 template <typename T> __device__ __forceinline__ float cvt_in(T v) { return (float)v; }
+template <> __device__ __forceinline__ float cvt_in<xf32>(xf32 v) { return v.v; }
 
 // store 4 consecutive outputs
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
+}
+__device__ __forceinline__ void store4(xf32* p, float a, float b, float c, float d) {
     *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
 }
 __device__ __forceinline__ void store4(bf16* p, float a, float b, float c, float d) {

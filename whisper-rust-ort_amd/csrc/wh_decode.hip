@@ -1296,6 +1296,7 @@ void launch_dec_gemm_split(hipStream_t s, const SkinnyArgs& a) {
 
 void wh_launch_dec_gemm(hipStream_t s, int prec, bool out_f32, const SkinnyArgs& a) {
     if (prec == WH_PREC_F32) launch_dec_gemm_split<float, float, float>(s, a);
+    else if (prec == WH_PREC_F16X3) launch_dec_gemm_split<xf32, float, xf32>(s, a);   // f32 storage, fp16 limbs at the fragment loads
     else if (prec == WH_PREC_FP8 && a.wscale) {  // e4m3 weight codes, bf16 activations
         // 16 codes per lane per load when every wave's K share is a multiple of 64, else 8
         const int nw = dec_gemm_8way(a) ? 8 : 4;
@@ -1309,7 +1310,7 @@ void wh_launch_dec_gemm(hipStream_t s, int prec, bool out_f32, const SkinnyArgs&
 void wh_launch_dec_embed(hipStream_t s, int prec, const void* tok_emb, const float* pos_emb, const int* feed, int feed_ld,
                          const int* pos_p, float* x, void* xslab, float* stats, int rows, int d, int mpad, const float* xgamma) {
     dim3 grid((rows + 3) / 4);
-    if (prec == WH_PREC_F32)
+    if (prec == WH_PREC_F32 || prec == WH_PREC_F16X3)
         hipLaunchKernelGGL(k_dec_embed<float>, grid, dim3(256), 0, s, (const float*)tok_emb, pos_emb, feed, feed_ld, pos_p, x, (float*)xslab, stats, rows, d, mpad, xgamma);
     else
         hipLaunchKernelGGL(k_dec_embed<bf16>, grid, dim3(256), 0, s, (const bf16*)tok_emb, pos_emb, feed, feed_ld, pos_p, x, (bf16*)xslab, stats, rows, d, mpad, xgamma);
@@ -1346,6 +1347,7 @@ void launch_lm_head_t(hipStream_t s, const SkinnyArgs& a, int* n_parts_out = nul
 // a.X = final-LayerNorm'ed rows [M][K] in the compute dtype
 void wh_launch_lm_head(hipStream_t s, int prec, const SkinnyArgs& a) {
     if (prec == WH_PREC_F32) launch_lm_head_t<float>(s, a);
+    else if (prec == WH_PREC_F16X3) launch_lm_head_t<xf32>(s, a);
     else if (wh_lm_head_tile_applicable(a)) wh_launch_lm_head_tile(s, a);   // hundreds of rows: 256 x 256 tiles (wh_gemm8.hip), same logits
     else launch_lm_head_t<bf16>(s, a);
 }
@@ -1353,7 +1355,7 @@ void wh_launch_lm_head(hipStream_t s, int prec, const SkinnyArgs& a) {
 // number of argmax partials per row the LM head writes for this shape (its layout is [part][x_mpad])
 int wh_lm_head_parts(int prec, const SkinnyArgs& a) {
     int n = 0;
-    if (prec == WH_PREC_F32) launch_lm_head_t<float>(nullptr, a, &n);
+    if (prec == WH_PREC_F32 || prec == WH_PREC_F16X3) launch_lm_head_t<float>(nullptr, a, &n);
     else if (wh_lm_head_tile_applicable(a)) n = wh_lm_head_tile_parts(a);
     else launch_lm_head_t<bf16>(nullptr, a, &n);
     return n;
@@ -1361,14 +1363,14 @@ int wh_lm_head_parts(int prec, const SkinnyArgs& a) {
 
 void wh_launch_argmax_finish(hipStream_t s, int prec, const float* part_val, const int* part_idx, int n_parts, int mpad, int* pos_p,
                              int* ticket, const DecodeState& st, int B, const NextEmbed& ne) {
-    if (prec == WH_PREC_F32) hipLaunchKernelGGL(k_argmax_finish<float>, dim3(B), dim3(256), 0, s, part_val, part_idx, n_parts, mpad, pos_p, ticket, st, ne);
+    if (prec == WH_PREC_F32 || prec == WH_PREC_F16X3) hipLaunchKernelGGL(k_argmax_finish<float>, dim3(B), dim3(256), 0, s, part_val, part_idx, n_parts, mpad, pos_p, ticket, st, ne);
     else hipLaunchKernelGGL(k_argmax_finish<bf16>, dim3(B), dim3(256), 0, s, part_val, part_idx, n_parts, mpad, pos_p, ticket, st, ne);
 }
 
 void wh_launch_dec_self_attn(hipStream_t s, int prec, const void* qkv, void* kc, void* vc, void* out, const int* pos_p,
                              int d, int n_heads, int tc, int B, int mpad) {
     dim3 grid(n_heads, B);
-    if (prec == WH_PREC_F32)
+    if (prec == WH_PREC_F32 || prec == WH_PREC_F16X3)
         hipLaunchKernelGGL(k_dec_self_attn<float>, grid, dim3(64), 0, s, (const float*)qkv, (float*)kc, (float*)vc, (float*)out, pos_p, d, n_heads, tc, mpad);
     else
         hipLaunchKernelGGL(k_dec_self_attn<bf16>, grid, dim3(64), 0, s, (const bf16*)qkv, (bf16*)kc, (bf16*)vc, (bf16*)out, pos_p, d, n_heads, tc, mpad);
@@ -1390,7 +1392,8 @@ size_t wh_cross_lds_reserve(long total_wgs, size_t own_bytes) {
 void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void* ck, const void* cv, float* part,
                               float* ml, int S, int d, int n_heads, int splits, int B, void* out, int mpad, bool stream_nt) {
     dim3 grid(splits, B);
-    const long wgs = (long)splits * B * ((prec != WH_PREC_F32 && d > 512 && d % 256 == 0) ? d / 256 : 1);
+    const bool f32_layout = prec == WH_PREC_F32 || prec == WH_PREC_F16X3;   // (no matrix-core work in this kernel: the f32 form serves both)
+    const long wgs = (long)splits * B * ((!f32_layout && d > 512 && d % 256 == 0) ? d / 256 : 1);
     const size_t sm = wh_cross_lds_reserve(wgs, sizeof(float) * ((size_t)8 * n_heads + 4 * (size_t)d));
 #define WH_CA1(T_, N_, U_, NT_) do { set_max_smem(k_dec_cross_attn<T_, N_, U_, NT_>, sm);                                                 \
                                      hipLaunchKernelGGL((k_dec_cross_attn<T_, N_, U_, NT_>), grid, dim3(256), sm, s, (const T_*)q, (const T_*)ck, \
@@ -1398,7 +1401,7 @@ void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void
     static const int nt_env = [] { const char* e = getenv("WH_CROSS_NT"); return e ? atoi(e) : -1; }();   // (A/B runs: force the non-temporal K/V loads off / on)
     if (nt_env >= 0) stream_nt = nt_env != 0;
 #define WH_CA(T_, N_, U_) do { if (stream_nt) WH_CA1(T_, N_, U_, true); else WH_CA1(T_, N_, U_, false); } while (0)
-    if (prec == WH_PREC_F32) {
+    if (f32_layout) {
         const int nch = (d / 4 + 63) / 64;  // f32: 4 elements per chunk
         if (nch == 1) WH_CA(float, 1, 4);
         else if (nch == 2) WH_CA(float, 2, 2);

@@ -27,6 +27,7 @@ namespace {
 template <typename T> struct Tile;  // K-step depth and LDS row stride (elements) per compute dtype
 template <> struct Tile<bf16> { static constexpr int BK = 64, LDK = 72; };   // 144 B rows
 template <> struct Tile<float> { static constexpr int BK = 32, LDK = 36; };  // 144 B rows
+template <> struct Tile<xf32> { static constexpr int BK = 32, LDK = 36; };   // WH_PREC_F16X3: f32 tiles, split into fp16 limbs at the fragment load
 
 template <typename T, typename TO, int BM, int BN>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
@@ -334,34 +335,44 @@ void launch_gemm_t(hipStream_t s, const GemmArgs& g) {
 
 }  // namespace
 
-void wh_launch_gemm(hipStream_t s, int prec, bool out_f32, const GemmArgs& g) {
+bool wh_gemm8_enabled() {
     static const bool use8 = getenv("WH_GEMM8") == nullptr || atoi(getenv("WH_GEMM8")) != 0;   // WH_GEMM8=0: A/B against k_gemm
-    if (prec != WH_PREC_F32 && use8 && !g.small_ctx && wh_gemm8_applicable(g)) {
-        wh_launch_gemm8(s, out_f32, g);
-        return;
-    }
+    return use8;
+}
+
+int wh_launch_gemm(hipStream_t s, int prec, bool out_f32, const GemmArgs& g) {
+    if (prec != WH_PREC_F32 && prec != WH_PREC_F16X3 && wh_gemm8_enabled() && !g.small_ctx && wh_gemm8_applicable(g)) return wh_launch_gemm8(s, out_f32, g);
     if (g.ln_mode || g.xb_out || g.stats_out) {   // only k_gemm8 implements the LayerNorm fold: never drop it silently
         wh_set_error("GEMM with a folded LayerNorm (M %d N %d K %d) must run on k_gemm8", g.M, g.N, g.K);
-        return;
+        return WH_ERR_UNSUPPORTED;
+    }
+    const int bk = (prec == WH_PREC_F32 || prec == WH_PREC_F16X3) ? Tile<float>::BK : Tile<bf16>::BK;
+    if ((g.K % bk) != 0 || (g.n_per < g.N && (g.n_per % 128) != 0)) {
+        wh_set_error("k_gemm: K %d must be a multiple of %d and a column plane (%d) a multiple of the 128-column tile", g.K, bk, g.n_per);
+        return WH_ERR_UNSUPPORTED;
     }
     if (prec == WH_PREC_F32) {
         launch_gemm_t<float, float>(s, g);
+    } else if (prec == WH_PREC_F16X3) {
+        launch_gemm_t<xf32, float>(s, g);
     } else {
         if (out_f32) launch_gemm_t<bf16, float>(s, g);
         else launch_gemm_t<bf16, bf16>(s, g);
     }
+    return WH_OK;
 }
 
 void wh_launch_layernorm_blocks(hipStream_t s, int prec, const float* x, const float* w, const float* b, void* y, long rows, int d, int in_blk,
                                 int out_blk) {
     dim3 grid((unsigned)((rows + 3) / 4));
-    if (prec != WH_PREC_F32 && (d == 512 || d == 1024) && getenv("WH_LN_W8_OFF") == nullptr) {
+    const bool f32_layout = prec == WH_PREC_F32 || prec == WH_PREC_F16X3;
+    if (!f32_layout && (d == 512 || d == 1024) && getenv("WH_LN_W8_OFF") == nullptr) {
         dim3 g8((unsigned)((rows + 7) / 8));
         if (d == 512) hipLaunchKernelGGL(k_layernorm_w8<1>, g8, dim3(256), 0, s, x, w, b, (bf16*)y, rows, d, in_blk, out_blk);
         else hipLaunchKernelGGL(k_layernorm_w8<2>, g8, dim3(256), 0, s, x, w, b, (bf16*)y, rows, d, in_blk, out_blk);
         return;
     }
-    if (prec == WH_PREC_F32) hipLaunchKernelGGL(k_layernorm<float>, grid, dim3(256), 0, s, x, w, b, (float*)y, rows, d, in_blk, out_blk);
+    if (f32_layout) hipLaunchKernelGGL(k_layernorm<float>, grid, dim3(256), 0, s, x, w, b, (float*)y, rows, d, in_blk, out_blk);
     else hipLaunchKernelGGL(k_layernorm<bf16>, grid, dim3(256), 0, s, x, w, b, (bf16*)y, rows, d, in_blk, out_blk);
 }
 

@@ -634,10 +634,14 @@ void wh_launch_ln_stats(hipStream_t s, const float* partials, int groups, long r
     hipLaunchKernelGGL(k_ln_stats, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, partials, groups, rows, 1.0f / (float)d, stat);
 }
 
-void wh_launch_gemm8(hipStream_t s, bool out_f32, const GemmArgs& g) {
+int wh_launch_gemm8(hipStream_t s, bool out_f32, const GemmArgs& g) {
+    if (!wh_gemm8_applicable(g)) {
+        wh_set_error("k_gemm8: geometry M %d N %d K %d not covered", g.M, g.N, g.K);
+        return WH_ERR_UNSUPPORTED;
+    }
     if ((g.xb_out || g.stats_out) && (!out_f32 || (g.N % 64) != 0 || g.n_per < g.N || (g.m_per < g.M && g.c_bs != (long)g.m_per * g.ldc) || g.batch != 1)) {
         wh_set_error("k_gemm8: LayerNorm-producer outputs need an f32 result with contiguous rows and N a multiple of 64");
-        return;
+        return WH_ERR_UNSUPPORTED;
     }
     // measured per shape (tools/gemm8_ablate.hip): the GELU epilogue is VALU work that a second workgroup on the CU hides
     // under its own MFMAs (fc1: 1.30 ms with BN = 128 against 1.43 ms); everything else is faster or equal with the larger
@@ -646,12 +650,13 @@ void wh_launch_gemm8(hipStream_t s, bool out_f32, const GemmArgs& g) {
     if (g.ln_mode) {   // consumers of a folded LayerNorm: bf16 results only, no channel scale (the bf16 encoder path)
         if (out_f32 || g.wscale || !g.ln_stat || !g.ln_s || (g.ln_mode == 1 && g.bias_mode != 1) || (g.ln_mode == 2 && (g.bias_mode != 2 || (g.N % 4) != 0))) {
             wh_set_error("k_gemm8: unsupported LayerNorm-fold arguments (mode %d)", g.ln_mode);
-            return;
+            return WH_ERR_UNSUPPORTED;
         }
         if (g.ln_mode == 1) { if (wide) launch8<bf16, 256, 1>(s, g); else launch8<bf16, 128, 1>(s, g); }
         else { if (wide) launch8<bf16, 256, 2>(s, g); else launch8<bf16, 128, 2>(s, g); }
-        return;
+        return WH_OK;
     }
     if (out_f32) { if (wide) launch8<float, 256>(s, g); else launch8<float, 128>(s, g); }
     else { if (wide) launch8<bf16, 256>(s, g); else launch8<bf16, 128>(s, g); }
+    return WH_OK;
 }

@@ -394,17 +394,18 @@ bool wh_gemm8_mx_applicable(const GemmArgs& g) {
 }
 
 // out: 0 = bf16, 1 = f32, 2 = MX (codes + exponents in g.c_sc)
-void wh_launch_gemm8_mx(hipStream_t s, int out, const GemmArgs& g) {
+int wh_launch_gemm8_mx(hipStream_t s, int out, const GemmArgs& g) {
     if (!wh_gemm8_mx_applicable(g)) {   // the geometry guarantees live in one place; callers decide from the context (mx_ok)
         wh_set_error("k_gemm8_mx: geometry M %d N %d K %d not covered", g.M, g.N, g.K);
-        return;
+        return WH_ERR_UNSUPPORTED;
     }
     if (out == 2) launch_mx<MxOut>(s, g);
     else if (out == 1) launch_mx<float>(s, g);
     else launch_mx<bf16>(s, g);
+    return WH_OK;
 }
 
-void wh_launch_layernorm_mx(hipStream_t s, const float* x, const float* w, const float* b, void* codes, void* exps, long rows, int d) {
+int wh_launch_layernorm_mx(hipStream_t s, const float* x, const float* w, const float* b, void* codes, void* exps, long rows, int d) {
     dim3 grid((unsigned)((rows + 3) / 4));
     unsigned char *cp = (unsigned char*)codes, *ep = (unsigned char*)exps;
     switch (d) {   // the MX path exists for these widths only (wh_api.cpp: mx_ok)
@@ -414,6 +415,7 @@ void wh_launch_layernorm_mx(hipStream_t s, const float* x, const float* w, const
         case 1280: hipLaunchKernelGGL(k_layernorm_mx<5>, grid, dim3(256), 0, s, x, w, b, cp, ep, rows); break;
         case 1536: hipLaunchKernelGGL(k_layernorm_mx<6>, grid, dim3(256), 0, s, x, w, b, cp, ep, rows); break;
         case 2048: hipLaunchKernelGGL(k_layernorm_mx<8>, grid, dim3(256), 0, s, x, w, b, cp, ep, rows); break;
-        default: wh_set_error("k_layernorm_mx: unsupported width %d", d); break;
+        default: wh_set_error("k_layernorm_mx: unsupported width %d", d); return WH_ERR_UNSUPPORTED;
     }
+    return WH_OK;
 }

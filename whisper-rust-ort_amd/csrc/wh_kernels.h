@@ -133,12 +133,15 @@ void wh_launch_mel_tokens(hipStream_t s, const float* src, long src_clip_stride,
                           const int* src_index, const int* frame_start, const int* n_frames_src, const unsigned* gmax,
                           int mode, int n_mels, int n_out, T* tok, long tok_clip_stride);
 
-void wh_launch_gemm(hipStream_t s, int prec, bool out_f32, const GemmArgs& g);
+// The GEMM launchers return WH_OK or an error code with the reason in wh_set_error: a launch that cannot run as asked is
+// reported to the caller, never skipped silently (run_encoder / run_decode propagate it).
+int wh_launch_gemm(hipStream_t s, int prec, bool out_f32, const GemmArgs& g);
+bool wh_gemm8_enabled();   // false under WH_GEMM8=0 (A/B switch): every GEMM on k_gemm, so no folded LayerNorm either
 // wh_gemm8.hip: the 8-wave LDS-DMA kernel (bf16 operands) for problems with at least one full 256 x 128 tile
 bool wh_gemm8_applicable(const GemmArgs& g);
 // {mean, rstd} per row from the producers' partial sums: stat[row][2] <- partials[groups][rows][2] (groups added in order)
 void wh_launch_ln_stats(hipStream_t s, const float* partials, int groups, long rows, int d, float* stat);
-void wh_launch_gemm8(hipStream_t s, bool out_f32, const GemmArgs& g);
+int wh_launch_gemm8(hipStream_t s, bool out_f32, const GemmArgs& g);
 // MX block exponents of a [rows][K] operand: [row][4][nkp] bytes, nkp = K-steps of 128 rounded up to a multiple of 4 (from 4 on)
 // so that the bytes of 16 consecutive K-steps are four aligned dwords
 __host__ __device__ inline int wh_mx_nkp(int K) { const int nk = K >> 7; return nk < 4 ? nk : (nk + 3) / 4 * 4; }
@@ -146,8 +149,8 @@ inline bool wh_mx_ln_width(int d) { return d == 256 || d == 512 || d == 1024 || 
 // wh_gemm8_mx.hip: e4m3 x e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4 (out: 0 bf16, 1 f32, 2 MX codes + exponents), and the
 // LayerNorm that produces MX activations
 bool wh_gemm8_mx_applicable(const GemmArgs& g);
-void wh_launch_gemm8_mx(hipStream_t s, int out, const GemmArgs& g);
-void wh_launch_layernorm_mx(hipStream_t s, const float* x, const float* w, const float* b, void* codes, void* exps, long rows, int d);
+int wh_launch_gemm8_mx(hipStream_t s, int out, const GemmArgs& g);
+int wh_launch_layernorm_mx(hipStream_t s, const float* x, const float* w, const float* b, void* codes, void* exps, long rows, int d);
 void wh_launch_layernorm(hipStream_t s, int prec, const float* x, const float* w, const float* b, void* y, long rows,
                          int d);
 // the same with the output in blocks: input rows [i * in_blk, (i + 1) * in_blk) go to output rows i * out_blk ...  (in_blk == 0: contiguous)

@@ -465,7 +465,7 @@ struct Stager {
 }  // namespace
 
 int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device, int precision, wh_model** out, const WhPreQuant* pre) {
-    if (precision != WH_PREC_F32 && precision != WH_PREC_BF16 && precision != WH_PREC_FP8) {
+    if (precision != WH_PREC_F32 && precision != WH_PREC_BF16 && precision != WH_PREC_FP8 && precision != WH_PREC_F16X3) {
         wh_set_error("unsupported precision %d", precision);
         return WH_ERR_UNSUPPORTED;
     }
@@ -488,7 +488,7 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     m->dims = c;
     m->prec = precision;
     m->device = device;
-    m->esz = precision == WH_PREC_F32 ? 4 : 2;
+    m->esz = (precision == WH_PREC_F32 || precision == WH_PREC_F16X3) ? 4 : 2;   // WH_PREC_F16X3: f32 storage, fp16 limbs made at the fragment loads
     m->master = std::move(master_in);
     TensorTable tt;
     wh_tensor_table(c, tt);

@@ -83,7 +83,7 @@ static bool parse_args(int argc, char** argv, Args& a) {
                    "[--task transcribe] [--max-new-tokens 128] [--warmup 0] [--limit-files 0] [--discovery-best-json F] "
                    "[--out-csv F] [--out-json F] [--out-summary-json F] [--intra-op N] [--inter-op N] [--write-txt] "
                    "[--tokenizer-json F] [--timestamps] [--chunk-parallelism N] [--chunk-length-s 30] [--overlap-s 5] "
-                   "[--device 0] [--devices 0-7] [--streams-per-gpu 1] [--load-threads N] [--precision bf16|f32|fp8] [--max-batch 16] "
+                   "[--device 0] [--devices 0-7] [--streams-per-gpu 1] [--load-threads N] [--precision bf16|f32|fp8|f16x3] [--max-batch 16] "
                    "[--synthetic-clips N] [--seed 1000]\n");
             exit(0);
         } else {
@@ -328,7 +328,7 @@ int main(int argc, char** argv) {
         GenCfg gen = load_generation_cfg(a.onnx_dir + "/generation_config.json");
         if (!synthetic_model && !is_dir(a.onnx_dir)) throw std::runtime_error("onnx_dir does not exist or is not a directory: " + a.onnx_dir);
 
-        const int prec = a.precision == "f32" ? WH_PREC_F32 : a.precision == "fp8" ? WH_PREC_FP8 : WH_PREC_BF16;
+        const int prec = a.precision == "f32" ? WH_PREC_F32 : a.precision == "fp8" ? WH_PREC_FP8 : a.precision == "f16x3" ? WH_PREC_F16X3 : WH_PREC_BF16;
         // One model per device (the reference shares its three `&Session`s across the rayon pool, src/main.rs:890-919),
         // `--streams-per-gpu` contexts per model, one host thread per context; files are independent units
         // (src/main.rs:1164 loops over them serially) and are dealt to whichever context is free.
