@@ -183,7 +183,7 @@ def main() -> None:
                     help="token-loop cross-attention on the encoder states (wh_cross_es.hip) instead of the projected K / V cache; "
                          "auto = the library's rule (bf16 whisper-base geometry, contexts of >= 256 clips)")
     ap.add_argument("--preset", default="base")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "fp8"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "fp8", "f16x3"])
     ap.add_argument("--max-new-tokens", type=int, default=128)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -264,7 +264,7 @@ def main() -> None:
 
     dims = ms.PRESETS[a.preset]
     prec = wb.PRECISIONS[a.precision]
-    esz = 4 if prec == wb.WH_PREC_F32 else 2
+    esz = 4 if prec in (wb.WH_PREC_F32, wb.WH_PREC_F16X3) else 2
     if wb.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: libwhisper_hip has no CPU fallback")
     if a.clips <= 0:   # the largest device batch whose workspace + caches fit comfortably
@@ -512,7 +512,8 @@ def main() -> None:
         d_, F_, T_, Le_ = dims.d_model, dims.ffn, dims.n_audio_ctx, dims.enc_layers
         attn_flop = Le_ * 2 * 2 * T_ * T_ * d_ * a.clips
         gemm_flop = work["enc_flop_per_clip"] * a.clips - attn_flop
-        mfma_peak = 2500.0 if prec != wb.WH_PREC_F32 else 2500.0 / 16.0   # TFLOP/s dense bf16; exact-f32 MFMA is 1/16 of it
+        # TFLOP/s dense bf16 / fp16; exact-f32 MFMA is 1/16 of it; the split-fp16 mode spends three fp16 MFMAs per product
+        mfma_peak = {wb.WH_PREC_F32: 2500.0 / 16.0, wb.WH_PREC_F16X3: 2500.0 / 3.0}.get(prec, 2500.0)
 
         def sec(bound, work_units, ms, peak, unit, note):
             ach = work_units / (ms * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9) if ms > 0 else 0.0

@@ -38,6 +38,11 @@ def H():
     L.whh_stitch.restype = C.c_size_t
     L.whh_word_overlap.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
     L.whh_word_overlap.restype = C.c_size_t
+    L.whh_summary_json.argtypes = [C.POINTER(C.c_double), C.c_size_t, C.c_char_p, C.POINTER(C.c_longlong), C.c_uint, C.c_char_p, C.c_size_t]
+    L.whh_summary_json.restype = C.c_size_t
+    for f in (L.whh_lower, L.whh_trim):
+        f.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        f.restype = C.c_size_t
     L.whh_decode_tokens.argtypes = [C.POINTER(C.c_longlong), C.c_size_t, C.c_char_p, C.c_char_p, C.c_size_t]
     L.whh_decode_tokens.restype = C.c_size_t
     L.whh_special_tokens.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_longlong)]
@@ -179,6 +184,109 @@ def test_stitcher(H):
     chunks = b"  Hello there general \0general Kenobi you are\0\0 you are a bold one \0unrelated tail\0"
     assert _s(H.whh_stitch, chunks, 5) == "Hello there general Kenobi you are a bold one unrelated tail"
     assert _s(H.whh_stitch, b"only\0", 1) == "only" and _s(H.whh_stitch, b"\0 \0", 2) == ""
+
+
+def test_stitcher_is_unicode_aware_like_rust(H):
+    """src/main.rs:663, 671, 686-688: trim / split_whitespace split on the Unicode White_Space property and to_lowercase maps every
+    cased letter (with the final-sigma rule) — not ASCII only."""
+    ov = lambda a, b, k=16: H.whh_word_overlap(a.encode(), b.encode(), k)
+    assert ov("bonjour à l'École", "l'école primaire") == 1 and ov("rentrée ÉCOLE", "école primaire") == 1   # É -> é
+    assert ov("ΚΑΛΗΜΕΡΑ ΚΟΣΜΟΣ", "κόσμος") == 0 and ov("καλημέρα ΚΟΣΜΟΣ", "κοσμος και") == 1   # final sigma: ΚΟΣΜΟΣ -> κοσμος
+    assert ov("ПРИВЕТ МИР", "мир вам") == 1                                    # Cyrillic
+    assert ov("a\u00a0b\u3000c", "B C d") == 2                                 # NO-BREAK SPACE and IDEOGRAPHIC SPACE separate words
+    assert ov("İstanbul", "i\u0307stanbul'da") == 0 and ov("gel İSTANBUL", "i\u0307stanbul güzel") == 1   # U+0130 -> i + U+0307
+    st = lambda chunks: _s(H.whh_stitch, "\0".join(chunks).encode() + b"\0", len(chunks))
+    assert st(["\u3000Vive l'\u00c9cole\u00a0", "L'\u00e9cole\u2003libre\u2028"]) == "Vive l'\u00c9cole libre"   # trimmed, split and matched on Unicode rules
+    assert st(["\u00a0\u2009", "x"]) == "x"                                    # a chunk of nothing but Unicode spaces is empty (:664-666)
+    low = lambda t: _s(H.whh_lower, t.encode())
+    tr = lambda t: _s(H.whh_trim, t.encode())
+    for cp in list(range(1, 0x3000)) + list(range(0xFF00, 0xFF60)) + list(range(0x10400, 0x10450)):   # to_lowercase == Python's full mapping
+        if 0xD800 <= cp <= 0xDFFF:
+            continue
+        assert low(chr(cp)) == chr(cp).lower(), hex(cp)
+    for t in ("ΟΔΟΣ", "ΟΔΟΣ.", "ΣΑΣ", "Σ", "ΑΣ'Β", "STRASSE ẞ", "Ǆ ǅ ǆ"):
+        assert low(t) == t.lower(), t
+    assert tr("\u2028\u00a0 a b \u3000\u0085") == "a b" and tr("\u200b a") == "\u200b a"   # ZERO WIDTH SPACE is not White_Space
+
+
+# ------------------------------------------------------------------------------------------------
+# reference-held data (tests/golden/ref_emitters/: the reference's archived outputs, copied byte for byte): values parsed out of
+# them -> this repo's emitters -> the same bytes
+# ------------------------------------------------------------------------------------------------
+REF = os.path.join(ROOT, "tests", "golden", "ref_emitters")
+
+
+def _ref(name):
+    with open(os.path.join(REF, name), "rb") as f:
+        return f.read()
+
+
+def test_summary_json_round_trips_the_references_own_file(H):
+    """inference_summary.json as src/main.rs:1235-1257 wrote it on 4 EPYC cores -> the values in it -> reference_summary()
+    (the function whisper_bench calls) -> byte-identical text: key order (alphabetical: serde_json without preserve_order),
+    ryu float text (14.884440201999999), 2-space pretty printing, no trailing newline."""
+    raw = _ref("inference_summary.json")
+    j = json.loads(raw)
+    assert j["n_files"] == 1
+    blocks = [j["latency_end_to_end_s"], j["breakdown_s"]["load_s"], j["breakdown_s"]["preprocess_s"], j["breakdown_s"]["model_only_s"],
+              j["breakdown_s"]["decode_s"], j["rtf_end_to_end"]]
+    for b in blocks:                                   # one file: every statistic of a list is its only element (:1033-1048)
+        assert len({b[k] for k in ("min", "median", "p90", "p95", "max", "mean")}) == 1
+    lists = _d([b["p95"] for b in blocks])             # n = 1: [end2end | load | preprocess | model_only | decode | rtf]
+    cu = j["config_used"]
+    strs = "\0".join([j["model_id"], j["onnx_dir"], j["language"], j["task"], j["tokenizer_json"], cu["execution_mode"], cu["graph_opt"]]).encode() + b"\0"
+    ints = (C.c_longlong * 3)(cu["intra_op"], cu["inter_op"], j["max_new_tokens"])
+    flags = (1 if j["timestamps"] else 0) | (2 if cu["cpu_mem_arena"] else 0) | (4 if cu["mem_pattern"] else 0) | (8 if cu["allow_spinning"] else 0)
+    got = _s(H.whh_summary_json, lists, 1, strs, ints, flags)
+    assert got.encode() == raw
+    # end_to_end = load + the window loop's own wall time (:1190, :1005), which contains the three stage buckets
+    assert blocks[0]["p95"] >= blocks[1]["p95"] + blocks[2]["p95"] + blocks[3]["p95"] + blocks[4]["p95"]
+
+
+def test_per_file_emitters_round_trip_the_references_own_files(H):
+    """inference_per_file.json / .csv and the --write-txt transcript (src/main.rs:1193-1232): the unrounded inputs are recovered from
+    the summary (end_to_end and rtf are unrounded there; duration = end_to_end / rtf), make_row rounds them (3 / 4 / 6 places, half
+    away from zero) and both emitters reproduce the reference's files byte for byte — including the csv crate's quoting of the
+    4.6 KB transcript and serde_json's string escaping."""
+    summ = json.loads(_ref("inference_summary.json"))
+    rows = json.loads(_ref("inference_per_file.json"))
+    assert len(rows) == 1 and list(rows[0].keys()) == ["file", "duration_s", "end_to_end_s", "rtf", "text"]
+    e2e, rtf = summ["latency_end_to_end_s"]["p95"], summ["rtf_end_to_end"]["p95"]
+    dur = e2e / rtf
+    assert abs(dur - rows[0]["duration_s"]) <= 5e-4
+    files, texts = rows[0]["file"].encode() + b"\0", rows[0]["text"].encode() + b"\0"
+    buf = C.create_string_buffer(1 << 16)
+    n = H.whh_per_file_json(files, texts, _d([dur]), _d([e2e]), 1, buf, len(buf))
+    assert buf.raw[:n] == _ref("inference_per_file.json")
+    n = H.whh_csv(files, texts, _d([dur]), _d([e2e]), 1, buf, len(buf))
+    assert buf.raw[:n] == _ref("inference_per_file.csv")
+    assert (_s(H.whh_trim, rows[0]["text"].encode()) + "\n").encode() == _ref("audio.transcript.txt")      # :1208-1211
+
+
+def test_results_table_reproduces_the_references_aggregated_row(tmp_path):
+    """results_table.py on the reference's archived summary + /usr/bin/time log -> the row the reference's own
+    aggregation wrote into summary_table.csv / summary_table.md and RESULTS.csv (compare_container_benchmarks.py:118-226,
+    update_results_md.py:33-143): time 14.884 s from the summary's p95, 2126 MB from the log's maximum resident set size."""
+    import csv
+    import shutil
+    from whisper_rust_ort_amd import results_table as rt
+    run = tmp_path / "without_hf_pipeline_rust"
+    run.mkdir()
+    shutil.copy(os.path.join(REF, "inference_summary.json"), run / "inference_summary.json")
+    logs = tmp_path / "logs"
+    logs.mkdir()
+    shutil.copy(os.path.join(REF, "without_hf_pipeline_rust.time.txt"), logs / "without_hf_pipeline_rust.time.txt")
+    md, cs = tmp_path / "t.md", tmp_path / "t.csv"
+    label = "onnxruntime rust (no HF pipeline)"       # the reference's display name of this variant (compare_container_benchmarks.py:24-31)
+    assert rt.main(["--summary", f"{label}={run / 'inference_summary.json'}", "--log-dir", str(logs), "--out-md", str(md), "--out-csv", str(cs)]) == 0
+    want_csv = [l for l in _ref("summary_table.csv").decode().splitlines() if l.startswith(label)]
+    want_md = [l for l in _ref("summary_table.md").decode().splitlines() if l.startswith("| " + label)]
+    assert len(want_csv) == 1 and len(want_md) == 1
+    assert cs.read_text().splitlines() == [_ref("summary_table.csv").decode().splitlines()[0], want_csv[0]]
+    assert md.read_text().splitlines()[2] == want_md[0] and md.read_text().splitlines()[:2] == _ref("summary_table.md").decode().splitlines()[:2]
+    hist = [r for r in csv.DictReader(_ref("RESULTS.csv").decode().splitlines()) if r["implementation"] == label and r["core_count"] == "4"]
+    got = list(csv.DictReader(cs.open()))[0]
+    assert len(hist) == 1 and all(hist[0][k] == got[k] for k in ("implementation", "precision", "beam_size", "time_s", "ram_mb"))
 
 
 def test_prompt_ids_and_token_fallback(H, tmp_path):

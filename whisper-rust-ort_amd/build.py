@@ -85,7 +85,7 @@ def build_host(verbose: bool = False, force: bool = False) -> None:
     """The host side above the C ABI (C++, because the reference's host is compiled Rust and Rust is
     not in this image): the CLI `whisper_bench` and `libwh_host.so` (host helpers for the tests)."""
     gxx = os.environ.get("CXX", "g++")
-    hdr = [os.path.join(HOST, "wh_host.h"), os.path.join(CSRC, "wh_json.h"), os.path.join(HERE, "..", "include", "whisper_hip.h")]
+    hdr = [os.path.join(HOST, "wh_host.h"), os.path.join(HOST, "wh_unicode_lower.h"), os.path.join(CSRC, "wh_json.h"), os.path.join(HERE, "..", "include", "whisper_hip.h")]
     src = os.path.join(HOST, "wh_host_capi.cpp")
     if force or _stale(HOST_SO, [src] + hdr):
         cmd = [gxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", HOST_SO, src]

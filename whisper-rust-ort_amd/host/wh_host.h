@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../csrc/wh_json.h"
+#include "wh_unicode_lower.h"
 
 namespace whhost {
 
@@ -220,6 +221,31 @@ struct OrtCfg {  // :91-100 — CPU-EP knobs: accepted and echoed only, they hav
     }
 };
 
+// The summary object of src/main.rs:1235-1257, from the per-file lists of :1200-1205 — exactly the reference's keys (the
+// CLI appends its additive gpu{} / rtfx_end_to_end{} keys afterwards).  tests/test_host_cpu.py rebuilds the reference's own
+// archived inference_summary.json from its values through this function and requires the bytes to match.
+struct SummaryIn {
+    OrtCfg cfg;
+    std::vector<double> end2end, load, preprocess, model_only, decode, rtf;
+    size_t n_files = 0;
+    std::string model_id, onnx_dir, language, task, tokenizer_json;   // tokenizer_json: "" when none was loaded (:1250)
+    long long max_new_tokens = 128;
+    bool timestamps = false;
+};
+inline JVal reference_summary(const SummaryIn& in) {
+    JVal summary = JVal::obj();
+    summary.set("config_used", in.cfg.json(true)).set("n_files", JVal::integer((long long)in.n_files))
+        .set("latency_end_to_end_s", stat_json(stat_block(in.end2end)))
+        .set("breakdown_s", JVal::obj().set("load_s", stat_json(stat_block(in.load))).set("preprocess_s", stat_json(stat_block(in.preprocess)))
+                                .set("model_only_s", stat_json(stat_block(in.model_only))).set("decode_s", stat_json(stat_block(in.decode))))
+        .set("rtf_end_to_end", stat_json(stat_block(in.rtf))).set("model_id", JVal::str(in.model_id)).set("onnx_dir", JVal::str(in.onnx_dir))
+        .set("language", JVal::str(in.language)).set("task", JVal::str(in.task)).set("max_new_tokens", JVal::integer(in.max_new_tokens))
+        .set("tokenizer_json", JVal::str(in.tokenizer_json)).set("timestamps", JVal::boolean(in.timestamps))
+        .set("notes", JVal::obj().set("longform", JVal::str("Rust approximation: chunked 30s windows with overlap; greedy decode via decoder_with_past"))
+                          .set("token_decode", JVal::str(!in.tokenizer_json.empty() ? "Tokenizer decode (skip_special_tokens=true)" : "Prints token IDs unless you provide tokenizer.json.")));
+    return summary;
+}
+
 // ---------------------------------------------------------------------------------------------
 // audio — src/main.rs:207-316 (WAV container only; FLAC/MP3 are out of scope here)
 // ---------------------------------------------------------------------------------------------
@@ -397,18 +423,124 @@ inline std::string decode_tokens(const std::vector<int64_t>& tokens, const Token
 // ---------------------------------------------------------------------------------------------
 // long-form stitcher — src/main.rs:659-696
 // ---------------------------------------------------------------------------------------------
-inline std::vector<std::string> split_ws(const std::string& s) {
+// Rust's str::split_whitespace / trim split on the Unicode White_Space property and str::to_lowercase maps every cased
+// letter (src/main.rs:663, 671, 686-688 use all three): the helpers below decode UTF-8 and do the same — the White_Space set
+// in full, lowercase through the complete table of simple case mappings (wh_unicode_lower.h, generated from the Unicode
+// Character Database by tools/gen_unicode_lower.py), the one multi-character mapping (U+0130 -> "i" + U+0307) and the
+// contextual final sigma.
+inline size_t utf8_next(const std::string& s, size_t i, uint32_t* cp) {   // decodes one scalar value, returns its byte length (malformed: 1 byte, U+FFFD)
+    const unsigned char c = (unsigned char)s[i];
+    auto cont = [&](size_t k) { return i + k < s.size() && ((unsigned char)s[i + k] & 0xC0) == 0x80; };
+    if (c < 0x80) { *cp = c; return 1; }
+    if ((c & 0xE0) == 0xC0 && cont(1)) { *cp = ((c & 0x1Fu) << 6) | ((unsigned char)s[i + 1] & 0x3Fu); return 2; }
+    if ((c & 0xF0) == 0xE0 && cont(1) && cont(2)) { *cp = ((c & 0x0Fu) << 12) | (((unsigned char)s[i + 1] & 0x3Fu) << 6) | ((unsigned char)s[i + 2] & 0x3Fu); return 3; }
+    if ((c & 0xF8) == 0xF0 && cont(1) && cont(2) && cont(3)) {
+        *cp = ((c & 0x07u) << 18) | (((unsigned char)s[i + 1] & 0x3Fu) << 12) | (((unsigned char)s[i + 2] & 0x3Fu) << 6) | ((unsigned char)s[i + 3] & 0x3Fu);
+        return 4;
+    }
+    *cp = 0xFFFD;
+    return 1;
+}
+inline void utf8_put(std::string& o, uint32_t cp) {
+    if (cp < 0x80) o += (char)cp;
+    else if (cp < 0x800) { o += (char)(0xC0 | (cp >> 6)); o += (char)(0x80 | (cp & 0x3F)); }
+    else if (cp < 0x10000) { o += (char)(0xE0 | (cp >> 12)); o += (char)(0x80 | ((cp >> 6) & 0x3F)); o += (char)(0x80 | (cp & 0x3F)); }
+    else { o += (char)(0xF0 | (cp >> 18)); o += (char)(0x80 | ((cp >> 12) & 0x3F)); o += (char)(0x80 | ((cp >> 6) & 0x3F)); o += (char)(0x80 | (cp & 0x3F)); }
+}
+inline bool is_unicode_ws(uint32_t c) {   // the White_Space property (char::is_whitespace)
+    return (c >= 0x09 && c <= 0x0D) || c == 0x20 || c == 0x85 || c == 0xA0 || c == 0x1680 || (c >= 0x2000 && c <= 0x200A) || c == 0x2028 ||
+           c == 0x2029 || c == 0x202F || c == 0x205F || c == 0x3000;
+}
+inline uint32_t lower_cp(uint32_t c) {   // simple lowercase mapping: the generated table (wh_unicode_lower.h), binary search over its runs
+    if (c < 0x80) return (c >= 'A' && c <= 'Z') ? c + 32 : c;
+    int lo = 0, hi = kLowerRunCount - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) / 2;
+        const LowerRun& r = kLowerRuns[mid];
+        if (c < r.first) hi = mid - 1;
+        else if (c > r.last) lo = mid + 1;
+        else return ((c - r.first) % r.stride) == 0 ? (uint32_t)((int32_t)c + r.delta) : c;
+    }
+    return c;
+}
+// cased / case-ignorable, as far as the final-sigma rule of str::to_lowercase needs them: a letter with a case mapping in either
+// direction is cased; apostrophes, full stop, colon, soft hyphen, combining marks (U+0300-036F) and modifier letters are ignorable
+inline bool is_cased(uint32_t c) {
+    if (lower_cp(c) != c) return true;
+    if ((c >= 'a' && c <= 'z') || (c >= 0xDF && c <= 0xFF && c != 0xF7) || c == 0xB5 || c == 0xAA || c == 0xBA) return true;
+    if ((c >= 0x100 && c <= 0x24F) || (c >= 0x3AC && c <= 0x3CE) || (c >= 0x430 && c <= 0x52F) || (c >= 0x561 && c <= 0x587) ||
+        (c >= 0x1E00 && c <= 0x1FFF) || (c >= 0xFF41 && c <= 0xFF5A)) return true;
+    return false;
+}
+inline bool is_case_ignorable(uint32_t c) {
+    return c == '\'' || c == '.' || c == ':' || c == '^' || c == '`' || c == 0xA8 || c == 0xAD || c == 0xAF || c == 0xB4 || c == 0xB7 || c == 0xB8 ||
+           c == 0x2019 || c == 0x2018 || (c >= 0x2B0 && c <= 0x36F) || (c >= 0x483 && c <= 0x489) || (c >= 0x200B && c <= 0x200F);
+}
+inline std::vector<std::string> split_ws(const std::string& s) {   // str::split_whitespace
     std::vector<std::string> w;
-    std::istringstream is(s);
-    std::string t;
-    while (is >> t) w.push_back(t);
+    std::string cur;
+    for (size_t i = 0; i < s.size();) {
+        uint32_t cp;
+        const size_t n = utf8_next(s, i, &cp);
+        if (is_unicode_ws(cp)) { if (!cur.empty()) { w.push_back(cur); cur.clear(); } }
+        else cur.append(s, i, n);
+        i += n;
+    }
+    if (!cur.empty()) w.push_back(cur);
     return w;
 }
-inline std::string lower(std::string s) { for (auto& c : s) c = (char)std::tolower((unsigned char)c); return s; }
-inline std::string trim(const std::string& s) {
+inline std::string lower(const std::string& s) {   // str::to_lowercase
+    std::string o;
+    for (size_t i = 0; i < s.size();) {
+        uint32_t cp;
+        const size_t n = utf8_next(s, i, &cp);
+        if (cp == 0xFFFD && n == 1 && (unsigned char)s[i] >= 0x80) o += s[i];        // malformed byte: passed through
+        else if (cp == 0x130) { o += 'i'; utf8_put(o, 0x307); }
+        else if (cp == 0x3A3) {
+            // final sigma (the one contextual rule of str::to_lowercase): preceded by a cased letter and not followed by one,
+            // case-ignorable characters skipped on both sides -> U+03C2, else U+03C3
+            bool before = false, after = false;
+            for (size_t q = i; q > 0;) {
+                size_t b = q - 1;
+                while (b > 0 && ((unsigned char)s[b] & 0xC0) == 0x80) b--;
+                uint32_t pc;
+                utf8_next(s, b, &pc);
+                q = b;
+                if (is_case_ignorable(pc)) continue;
+                before = is_cased(pc);
+                break;
+            }
+            for (size_t q = i + n; q < s.size();) {
+                uint32_t nc;
+                const size_t m = utf8_next(s, q, &nc);
+                q += m;
+                if (is_case_ignorable(nc)) continue;
+                after = is_cased(nc);
+                break;
+            }
+            utf8_put(o, (before && !after) ? 0x3C2 : 0x3C3);
+        }
+        else utf8_put(o, lower_cp(cp));
+        i += n;
+    }
+    return o;
+}
+inline std::string trim(const std::string& s) {   // str::trim
     size_t a = 0, b = s.size();
-    while (a < b && std::isspace((unsigned char)s[a])) a++;
-    while (b > a && std::isspace((unsigned char)s[b - 1])) b--;
+    while (a < b) {
+        uint32_t cp;
+        const size_t n = utf8_next(s, a, &cp);
+        if (!is_unicode_ws(cp)) break;
+        a += n;
+    }
+    while (b > a) {   // step back one scalar value
+        size_t q = b - 1;
+        while (q > a && ((unsigned char)s[q] & 0xC0) == 0x80) q--;
+        uint32_t cp;
+        utf8_next(s, q, &cp);
+        if (!is_unicode_ws(cp)) break;
+        b = q;
+    }
     return s.substr(a, b - a);
 }
 inline size_t word_overlap(const std::string& a, const std::string& b, size_t max_words) {  // :686-696

@@ -43,6 +43,22 @@ size_t whh_csv(const char* files, const char* texts, const double* dur, const do
 size_t whh_per_file_json(const char* files, const char* texts, const double* dur, const double* e2e, size_t n, char* out, size_t cap) {
     return put(per_file_json(rows_from(files, texts, dur, e2e, n)), out, cap);
 }
+// the reference's summary object (src/main.rs:1235-1257) from per-file lists: lists = [end2end | load | preprocess | model_only | decode | rtf],
+// n values each; strs = NUL-separated model_id, onnx_dir, language, task, tokenizer_json, execution_mode, graph_opt;
+// ints = intra_op, inter_op, max_new_tokens; flags bit 0 timestamps, 1 cpu_mem_arena, 2 mem_pattern, 3 allow_spinning
+size_t whh_summary_json(const double* lists, size_t n, const char* strs, const long long* ints, unsigned flags, char* out, size_t cap) {
+    SummaryIn in;
+    auto take = [&](int k) { return std::vector<double>(lists + (size_t)k * n, lists + (size_t)(k + 1) * n); };
+    in.end2end = take(0); in.load = take(1); in.preprocess = take(2); in.model_only = take(3); in.decode = take(4); in.rtf = take(5);
+    in.n_files = n;
+    std::string* dst[7] = {&in.model_id, &in.onnx_dir, &in.language, &in.task, &in.tokenizer_json, &in.cfg.execution_mode, &in.cfg.graph_opt};
+    for (auto* d : dst) { *d = std::string(strs); strs += d->size() + 1; }
+    in.cfg.intra_op = ints[0]; in.cfg.inter_op = ints[1]; in.max_new_tokens = ints[2];
+    in.timestamps = flags & 1; in.cfg.cpu_mem_arena = flags & 2; in.cfg.mem_pattern = flags & 4; in.cfg.allow_spinning = flags & 8;
+    return put(reference_summary(in).pretty(), out, cap);
+}
+size_t whh_lower(const char* s, char* out, size_t cap) { return put(lower(s), out, cap); }
+size_t whh_trim(const char* s, char* out, size_t cap) { return put(trim(s), out, cap); }
 size_t whh_resample_linear(const float* x, size_t n, unsigned sr_in, unsigned sr_out, float* out, size_t cap) {
     std::vector<float> y = resample_linear(std::vector<float>(x, x + n), sr_in, sr_out);
     if (out) memcpy(out, y.data(), std::min(cap, y.size()) * sizeof(float));

@@ -469,18 +469,14 @@ int main(int argc, char** argv) {
         const double busy_max = *std::max_element(busy_s.begin(), busy_s.end());
         write_file(a.out_csv, csv_text(rows));
         write_file(a.out_json, per_file_json(rows));
-        JVal summary = JVal::obj();  // :1235-1257 (+ additive keys gpu, rtfx_end_to_end)
         std::vector<double> rtfx;
         for (double r : rtfl) rtfx.push_back(1.0 / std::max(r, 1e-12));
-        summary.set("config_used", cfg.json(true)).set("n_files", JVal::integer((long long)rows.size()))
-            .set("latency_end_to_end_s", stat_json(stat_block(e2e)))
-            .set("breakdown_s", JVal::obj().set("load_s", stat_json(stat_block(loadl))).set("preprocess_s", stat_json(stat_block(pre)))
-                                    .set("model_only_s", stat_json(stat_block(model_only))).set("decode_s", stat_json(stat_block(dec))))
-            .set("rtf_end_to_end", stat_json(stat_block(rtfl))).set("model_id", JVal::str(a.model_id)).set("onnx_dir", JVal::str(a.onnx_dir))
-            .set("language", JVal::str(a.language)).set("task", JVal::str(a.task)).set("max_new_tokens", JVal::integer((long long)a.max_new_tokens))
-            .set("tokenizer_json", JVal::str(tok.loaded ? tok.path : "")).set("timestamps", JVal::boolean(a.timestamps))
-            .set("notes", JVal::obj().set("longform", JVal::str("Rust approximation: chunked 30s windows with overlap; greedy decode via decoder_with_past"))
-                              .set("token_decode", JVal::str(tok.loaded ? "Tokenizer decode (skip_special_tokens=true)" : "Prints token IDs unless you provide tokenizer.json.")))
+        SummaryIn si;   // :1235-1257: the reference's keys from wh_host.h reference_summary (pinned to the reference's archived summary)
+        si.cfg = cfg; si.end2end = e2e; si.load = loadl; si.preprocess = pre; si.model_only = model_only; si.decode = dec; si.rtf = rtfl;
+        si.n_files = rows.size(); si.model_id = a.model_id; si.onnx_dir = a.onnx_dir; si.language = a.language; si.task = a.task;
+        si.tokenizer_json = tok.loaded ? tok.path : ""; si.max_new_tokens = (long long)a.max_new_tokens; si.timestamps = a.timestamps;
+        JVal summary = reference_summary(si);   // + additive keys gpu, rtfx_end_to_end
+        summary
             .set("rtfx_end_to_end", stat_json(stat_block(rtfx)))
             .set("gpu", JVal::obj().set("backend", JVal::str("libwhisper_hip (gfx950)")).set("device", JVal::integer(devices[0]))
                             .set("devices", JVal::integer((long long)devices.size())).set("streams_per_gpu", JVal::integer(a.streams_per_gpu))
