@@ -73,6 +73,39 @@ __device__ __forceinline__ void mma16(f32x4& acc, const xfrag& a, const xfrag& b
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, acc, 0, 0, 0);
 }
 
+// `h2`: the same operand already split, in memory.  32 consecutive k of a row take 128 bytes, [32 x fp16 hi | 32 x fp16 lo] — as many
+// bytes as the f32 values, so every pitch and offset of an h2 array is the f32 one (an h2* advances 4 bytes per element) and
+// the limbs of element k of a 128-byte-aligned 32-block sit at block + 2 (k % 32) and block + 64 + 2 (k % 32).  A fragment (8
+// consecutive k) is two 16-byte loads and no arithmetic; producers write the limbs (store4 / store8 / store1 below).  The
+// accessors take the ELEMENT address and find the block from its low seven bits, so kernels index h2 arrays exactly like
+// float arrays; every h2 array (global or LDS) therefore starts 128-byte aligned and keeps row pitches that are multiples of 32.
+struct h2 { unsigned v; };
+template <> struct FragT<h2> { typedef xfrag type; };
+__device__ __forceinline__ const char* h2_limb(const void* elem) {   // address of the element's hi limb (its lo limb: + 64)
+    const uintptr_t a = (uintptr_t)elem;
+    return reinterpret_cast<const char*>((a & ~(uintptr_t)127) + ((a & 127) >> 1));
+}
+template <>
+__device__ __forceinline__ xfrag load_frag<h2>(const h2* p) {   // p = element address of the fragment's first k (a multiple of 8)
+    const char* b = h2_limb(p);
+    xfrag r;
+    r.hi = *reinterpret_cast<const f16x8*>(b);
+    r.lo = *reinterpret_cast<const f16x8*>(b + 64);
+    return r;
+}
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+__device__ __forceinline__ f32x4 load4_f32(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4_f32(const xf32* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4_f32(const bf16* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ f32x4 load4_f32(const h2* p) {   // 4 consecutive elements as f32 (hi + lo: exact)
+    const char* b = h2_limb(p);
+    const f16x4 hi = *reinterpret_cast<const f16x4*>(b), lo = *reinterpret_cast<const f16x4*>(b + 64);
+    return f32x4{(float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]};
+}
+
 template <typename T> __device__ __forceinline__ T cvt_out(float v);
 template <> __device__ __forceinline__ xf32 cvt_out<xf32>(float v) { return xf32{v}; }
 template <> __device__ __forceinline__ float cvt_out<float>(float v) { return v; }
@@ -88,6 +121,22 @@ __device__ __forceinline__ void store4(float* p, float a, float b, float c, floa
 __device__ __forceinline__ void store4(xf32* p, float a, float b, float c, float d) {
     *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
 }
+__device__ __forceinline__ void store4(h2* p, float a, float b, float c, float d) {   // the limbs of 4 consecutive elements: two 8-byte stores
+    char* q = const_cast<char*>(h2_limb(p));
+    const f32x4 v = {a, b, c, d};
+    const f16x4 hi = __builtin_convertvector(v, f16x4);
+    const f16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
+    *reinterpret_cast<f16x4*>(q) = hi;
+    *reinterpret_cast<f16x4*>(q + 64) = lo;
+}
+__device__ __forceinline__ void store1(h2* p, float v) {
+    char* q = const_cast<char*>(h2_limb(p));
+    const _Float16 hi = (_Float16)v;
+    *reinterpret_cast<_Float16*>(q) = hi;
+    *reinterpret_cast<_Float16*>(q + 64) = (_Float16)(v - (float)hi);
+}
+__device__ __forceinline__ void store1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store1(bf16* p, float v) { *p = (bf16)v; }
 __device__ __forceinline__ void store4(bf16* p, float a, float b, float c, float d) {
     *reinterpret_cast<bf16x4*>(p) = bf16x4{(bf16)a, (bf16)b, (bf16)c, (bf16)d};
 }

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_dec_embed(const T* __restrict__ tok_emb
     float s1 = 0.0f, s2 = 0.0f;
     for (int c = lane * 4; c < d; c += 256) {
         f32x4 p = *reinterpret_cast<const f32x4*>(pr + c);
-        f32x4 v = {cvt_in<T>(er[c]) + p[0], cvt_in<T>(er[c + 1]) + p[1], cvt_in<T>(er[c + 2]) + p[2], cvt_in<T>(er[c + 3]) + p[3]};
+        f32x4 v = load4_f32(er + c) + p;
         *reinterpret_cast<f32x4*>(x + (long)row * d + c) = v;
         f32x4 g = {1, 1, 1, 1};
         if (xgamma) g = *reinterpret_cast<const f32x4*>(xgamma + c);  // fp8 mode: the first LayerNorm's γ rides on the slab copy
@@ -180,13 +180,13 @@ __device__ __forceinline__ void dec_gemm_group(SkinnyArgs& a) {
     if (z == 0) return;
     a.X = (const T*)a.X + z * a.x_zs;
     a.W = (const TW*)a.W + z * a.w_zs;
-    a.C = (TO*)a.C + z * a.c_zs;
+    a.C = a.c_mpad ? (void*)((T*)a.C + z * a.c_zs) : (void*)((TO*)a.C + z * a.c_zs);
     if (a.bias) a.bias += z * a.bias_zs;
 }
 
 template <typename T, typename TO, int MT, int NW, int XP, typename TW = T>  // XP > 0: X from XP-bounded attention partials
 __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    extern __shared__ __attribute__((aligned(128))) char smem_raw[];   // 128: h2 tiles find their 32-blocks from the address
     dec_gemm_group<T, TO, TW>(a);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fl = lane & 15, fg = lane >> 4;
@@ -200,7 +200,10 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
     // activation operand of (step i, sub-fragment j): slab (kb + i*KSTEP + fg*KW) / 32, offset (fg*KW) % 32 + 8j
     const long xstep = (long)a.x_mpad * 32 * (KSTEP / 32);
     const T* xp = XP > 0 ? nullptr : (const T*)a.X + ((long)((kb + fg * KW) >> 5) * a.x_mpad + m0 + fl) * 32 + ((fg * KW) & 31);
-    constexpr int DEPTH = 8 / SUB;
+    // k-steps in flight per wave: 8 for 16-byte fragments; 32-byte ones (f32, fp16 limbs) keep the register budget of MT = 1
+    // (8 x (1 + MT) fragments would spill from MT = 2 on: 1,074 spilled registers at MT = 4 before this rule)
+    constexpr int FRB = (int)sizeof(typename FragT<T>::type);
+    constexpr int DEPTH = FRB <= 16 ? 8 / SUB : (MT == 1 ? 8 : MT == 2 ? 4 : 2);
     typename FragT<T>::type wq[DEPTH][SUB], xq[DEPTH][SUB][MT];
 #pragma unroll
     for (int i = 0; i < DEPTH; i++)
@@ -334,8 +337,9 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
             if (a.act == 1) v[e] = gelu_erf(v[e]);
             v[e] += pre_r[e];
         }
-        TO* dst = a.c_mpad ? (TO*)a.C + slab_idx(em, en, a.c_mpad) : (TO*)a.C + (long)em * a.ldc + en;
-        store4(dst, v[0], v[1], v[2], v[3]);
+        // a slab output is another GEMM's operand: the compute type T (== TO wherever both are 2-byte); row-major outputs are TO
+        if (a.c_mpad) store4((T*)a.C + slab_idx(em, en, a.c_mpad), v[0], v[1], v[2], v[3]);
+        else store4((TO*)a.C + (long)em * a.ldc + en, v[0], v[1], v[2], v[3]);
         if (a.xslab_out) store4((T*)a.xslab_out + slab_idx(em, en, a.x_mpad), v[0] * pre_g[0], v[1] * pre_g[1], v[2] * pre_g[2], v[3] * pre_g[3]);
     }
     if (a.stats_out && wave < MT) {
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
 // (tile id = nt * MT + mt).  No merged-X (attention partials) variant: large batches run one key range per clip.
 template <typename T, typename TO, int MT, int NT, int NW, typename TW = T>
 __global__ __launch_bounds__(NW * 64, 2) void k_dec_gemm_wide(SkinnyArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    extern __shared__ __attribute__((aligned(128))) char smem_raw[];   // 128: h2 tiles find their 32-blocks from the address
     dec_gemm_group<T, TO, TW>(a);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fl = lane & 15, fg = lane >> 4;
@@ -387,7 +391,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_dec_gemm_wide(SkinnyArgs a) {
     for (int nt = 0; nt < NT; nt++) wp[nt] = (const TW*)a.W + (long)min(n0 + nt * 16 + fl, a.N - 1) * a.K + kb + fg * KW;
     const long xstep = (long)a.x_mpad * 32 * (KSTEP / 32);
     const T* xp = (const T*)a.X + ((long)((kb + fg * KW) >> 5) * a.x_mpad + m0 + fl) * 32 + ((fg * KW) & 31);
-    constexpr int DEPTH = 4 / SUB;  // four 32-deep k-slabs in flight per wave: (NT + MT) KiB each
+    // four 32-deep k-slabs in flight per wave: (NT + MT) KiB each; two with 32-byte fragments (the register file holds NT + MT of them per slab)
+    constexpr int DEPTH = sizeof(typename FragT<T>::type) <= 16 ? 4 / SUB : 2;
     typename FragT<T>::type wq[DEPTH][NT][SUB], xq[DEPTH][SUB][MT];
 #pragma unroll
     for (int i = 0; i < DEPTH; i++)
@@ -506,8 +511,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_dec_gemm_wide(SkinnyArgs a) {
                 if (a.act == 1) v[e] = gelu_erf(v[e]);
                 v[e] += pre_r[j][e];
             }
-            TO* dst = a.c_mpad ? (TO*)a.C + slab_idx(em[j], en[j], a.c_mpad) : (TO*)a.C + (long)em[j] * a.ldc + en[j];
-            store4(dst, v[0], v[1], v[2], v[3]);
+            if (a.c_mpad) store4((T*)a.C + slab_idx(em[j], en[j], a.c_mpad), v[0], v[1], v[2], v[3]);
+            else store4((TO*)a.C + (long)em[j] * a.ldc + en[j], v[0], v[1], v[2], v[3]);
             if (a.xslab_out) store4((T*)a.xslab_out + slab_idx(em[j], en[j], a.x_mpad), v[0] * pre_g[j][0], v[1] * pre_g[j][1], v[2] * pre_g[j][2], v[3] * pre_g[j][3]);
         }
         if (a.stats_out) {
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_dec_gemm_wide(SkinnyArgs a) {
 // embedding matrix with all of a tile's weight fragments in flight before its first MFMA.
 template <typename T, int MT>
 __global__ __launch_bounds__(256) void k_lm_head(SkinnyArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    extern __shared__ __attribute__((aligned(128))) char smem_raw[];   // 128: h2 tiles find their 32-blocks from the address
     constexpr int EPC = 16 / (int)sizeof(T);
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -596,7 +601,7 @@ __global__ __launch_bounds__(256) void k_lm_head(SkinnyArgs a) {
     // Pipeline unit = (tile, 16-fragment chunk of K).  Two register sets: the next unit's weight
     // fragments are in flight while the current unit's MFMAs issue.
     const int iters = a.K >> 5;
-    constexpr int DEPTH = 16;
+    constexpr int DEPTH = sizeof(typename FragT<T>::type) <= 16 ? 16 : 8;   // two register sets of DEPTH weight fragments
     const int nchunk = (iters + DEPTH - 1) / DEPTH;
     const int stride = gridDim.x * 4, first = blockIdx.x * 4 + wave;
     const int my_tiles = first < n_tiles ? (n_tiles - first + stride - 1) / stride : 0;
@@ -769,7 +774,7 @@ __global__ __launch_bounds__(256) void k_argmax_finish(const float* __restrict__
         float s1 = 0.0f, s2 = 0.0f;
         for (int c = tid * 4; c < ne.d; c += 1024) {
             const f32x4 p4 = *reinterpret_cast<const f32x4*>(pr + c);
-            const f32x4 v = {cvt_in<T>(er[c]) + p4[0], cvt_in<T>(er[c + 1]) + p4[1], cvt_in<T>(er[c + 2]) + p4[2], cvt_in<T>(er[c + 3]) + p4[3]};
+            const f32x4 v = load4_f32(er + c) + p4;
             *reinterpret_cast<f32x4*>(ne.x + (long)b * ne.d + c) = v;
             f32x4 g = {1, 1, 1, 1};
             if (ne.xgamma) g = *reinterpret_cast<const f32x4*>(ne.xgamma + c);
@@ -794,9 +799,9 @@ __global__ __launch_bounds__(256) void k_argmax_finish(const float* __restrict__
 // K cache [B][H][TC][64]  (lane j scores key j: its row is 8 x 16-byte loads, issued before anything else)
 // V cache [B][H][TC][64]  (lane e reads column e of every cached row: one 128-byte line per wave load)
 // The new k / v are appended (present.{i}.decoder.{key,value}) and used straight from registers.
-template <typename T>
+template <typename T, typename TO = T>   // TO: the attention output as the out-projection's operand (slab layout)
 __global__ __launch_bounds__(64) void k_dec_self_attn(const T* __restrict__ qkv, T* __restrict__ kc,
-                                                      T* __restrict__ vc, T* __restrict__ out,
+                                                      T* __restrict__ vc, TO* __restrict__ out,
                                                       const int* __restrict__ pos_p, int d, int n_heads, int tc,
                                                       int mpad) {
     constexpr int HD = WH_HEAD_DIM;
@@ -903,10 +908,14 @@ __global__ __launch_bounds__(64) void k_dec_self_attn(const T* __restrict__ qkv,
     }
     if (rslot == 0) {
         const float inv = 1.0f / sum;
-        vrow_t ov;
+        if constexpr (EPC == 4) {   // f32 caches: 4 columns per lane, in the operand type of the consumer
+            store4(out + slab_idx(b, h * HD + chunk * EPC, mpad), o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+        } else {
+            vrow_t ov;
 #pragma unroll
-        for (int e = 0; e < EPC; e++) ov[e] = cvt_out<T>(o[e] * inv);
-        *reinterpret_cast<vrow_t*>(out + slab_idx(b, h * HD + chunk * EPC, mpad)) = ov;
+            for (int e = 0; e < EPC; e++) ov[e] = cvt_out<T>(o[e] * inv);
+            *reinterpret_cast<vrow_t*>(out + slab_idx(b, h * HD + chunk * EPC, mpad)) = ov;
+        }
     }
 }
 
@@ -920,11 +929,11 @@ __global__ __launch_bounds__(64) void k_dec_self_attn(const T* __restrict__ qkv,
 // acquire around an arrival ticket) and writes the attention output.
 //   ck/cv: [B][S][d]  (head h at columns h*64..h*64+63),   q: [B][d] pre-scaled
 //   part : [B][splits][d] unnormalised partial outputs, ml: [B][splits][H][2] (max, sum)
-template <typename T, int NCH, int UNROLL, bool NT>  // NCH = ceil(d*sizeof(T)/16 / 64): 16-B chunks per lane per row; NT: non-temporal K/V loads
+template <typename T, int NCH, int UNROLL, bool NT, typename TO = T>  // NCH = ceil(d*sizeof(T)/16 / 64): 16-B chunks per lane per row; NT: non-temporal K/V loads; TO: type of the slab output
 __global__ __launch_bounds__(256) void k_dec_cross_attn(const T* __restrict__ q, const T* __restrict__ ck,
                                                         const T* __restrict__ cv, float* __restrict__ part,
                                                         float* __restrict__ ml, int S, int d, int n_heads,
-                                                        int splits, T* __restrict__ out, int mpad) {
+                                                        int splits, TO* __restrict__ out, int mpad) {
     constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-B chunk: 8 (bf16) / 4 (f32)
     constexpr int LPH = WH_HEAD_DIM / EPC;     // lanes per head: 8 / 16
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1083,7 +1092,7 @@ __global__ __launch_bounds__(256) void k_dec_cross_attn(const T* __restrict__ q,
             den += sc * wl[w * n_heads + h];
         }
         if (out) {  // one key range per clip: this IS the attention output (slab layout, compute dtype)
-            out[slab_idx(b, n, mpad)] = cvt_out<T>(num / den);
+            store1(out + slab_idx(b, n, mpad), num / den);
             continue;
         }
         pp[n] = num;
@@ -1230,7 +1239,7 @@ void launch_dec_gemm_mt(hipStream_t s, const SkinnyArgs& a) {
     if (wh_dbg_mt <= 0 && a.M > 64 && NW == 8 && !a.xpart) mt_cap = 2;  // fc2: 32-row groups (-0.5 %; 64 is slower again)
     // hundreds of rows (one key range per clip, so no merged X): NT column tiles per workgroup while >= 256 workgroups remain
     // (k_dec_gemm_wide; bit-identical results, so following the batch is allowed)
-    if constexpr (sizeof(T) == 2)   // (the exact-f32 mode keeps k_dec_gemm: its 8-register fragments do not fit NT x MT tiles)
+    if constexpr (!__is_same(T, float) && !__is_same(T, xf32))   // (f32 rows keep k_dec_gemm: the exact-f32 mode and the small-context form of the split-fp16 mode)
     if (a.M > 64 && !a.xpart && wh_dbg_mt <= 0 && a.K % (NW * 4 * WTraits<T, TW>::KW) == 0) {
         constexpr int WMT = 4;
         int wide = wh_dbg_wide;
@@ -1296,7 +1305,7 @@ void launch_dec_gemm_split(hipStream_t s, const SkinnyArgs& a) {
 
 void wh_launch_dec_gemm(hipStream_t s, int prec, bool out_f32, const SkinnyArgs& a) {
     if (prec == WH_PREC_F32) launch_dec_gemm_split<float, float, float>(s, a);
-    else if (prec == WH_PREC_F16X3) launch_dec_gemm_split<xf32, float, xf32>(s, a);   // f32 storage, fp16 limbs at the fragment loads
+    else if (prec == WH_PREC_F16X3) launch_dec_gemm_split<h2, float, h2>(s, a);   // operands as fp16 limbs (weights, slabs), f32 row-major results
     else if (prec == WH_PREC_FP8 && a.wscale) {  // e4m3 weight codes, bf16 activations
         // 16 codes per lane per load when every wave's K share is a multiple of 64, else 8
         const int nw = dec_gemm_8way(a) ? 8 : 4;
@@ -1310,7 +1319,9 @@ void wh_launch_dec_gemm(hipStream_t s, int prec, bool out_f32, const SkinnyArgs&
 void wh_launch_dec_embed(hipStream_t s, int prec, const void* tok_emb, const float* pos_emb, const int* feed, int feed_ld,
                          const int* pos_p, float* x, void* xslab, float* stats, int rows, int d, int mpad, const float* xgamma) {
     dim3 grid((rows + 3) / 4);
-    if (prec == WH_PREC_F32 || prec == WH_PREC_F16X3)
+    if (prec == WH_PREC_F16X3)
+        hipLaunchKernelGGL(k_dec_embed<h2>, grid, dim3(256), 0, s, (const h2*)tok_emb, pos_emb, feed, feed_ld, pos_p, x, (h2*)xslab, stats, rows, d, mpad, xgamma);
+    else if (prec == WH_PREC_F32)
         hipLaunchKernelGGL(k_dec_embed<float>, grid, dim3(256), 0, s, (const float*)tok_emb, pos_emb, feed, feed_ld, pos_p, x, (float*)xslab, stats, rows, d, mpad, xgamma);
     else
         hipLaunchKernelGGL(k_dec_embed<bf16>, grid, dim3(256), 0, s, (const bf16*)tok_emb, pos_emb, feed, feed_ld, pos_p, x, (bf16*)xslab, stats, rows, d, mpad, xgamma);
@@ -1347,7 +1358,7 @@ void launch_lm_head_t(hipStream_t s, const SkinnyArgs& a, int* n_parts_out = nul
 // a.X = final-LayerNorm'ed rows [M][K] in the compute dtype
 void wh_launch_lm_head(hipStream_t s, int prec, const SkinnyArgs& a) {
     if (prec == WH_PREC_F32) launch_lm_head_t<float>(s, a);
-    else if (prec == WH_PREC_F16X3) launch_lm_head_t<xf32>(s, a);
+    else if (prec == WH_PREC_F16X3) launch_lm_head_t<h2>(s, a);
     else if (wh_lm_head_tile_applicable(a)) wh_launch_lm_head_tile(s, a);   // hundreds of rows: 256 x 256 tiles (wh_gemm8.hip), same logits
     else launch_lm_head_t<bf16>(s, a);
 }
@@ -1363,14 +1374,17 @@ int wh_lm_head_parts(int prec, const SkinnyArgs& a) {
 
 void wh_launch_argmax_finish(hipStream_t s, int prec, const float* part_val, const int* part_idx, int n_parts, int mpad, int* pos_p,
                              int* ticket, const DecodeState& st, int B, const NextEmbed& ne) {
-    if (prec == WH_PREC_F32 || prec == WH_PREC_F16X3) hipLaunchKernelGGL(k_argmax_finish<float>, dim3(B), dim3(256), 0, s, part_val, part_idx, n_parts, mpad, pos_p, ticket, st, ne);
+    if (prec == WH_PREC_F16X3) hipLaunchKernelGGL(k_argmax_finish<h2>, dim3(B), dim3(256), 0, s, part_val, part_idx, n_parts, mpad, pos_p, ticket, st, ne);
+    else if (prec == WH_PREC_F32) hipLaunchKernelGGL(k_argmax_finish<float>, dim3(B), dim3(256), 0, s, part_val, part_idx, n_parts, mpad, pos_p, ticket, st, ne);
     else hipLaunchKernelGGL(k_argmax_finish<bf16>, dim3(B), dim3(256), 0, s, part_val, part_idx, n_parts, mpad, pos_p, ticket, st, ne);
 }
 
 void wh_launch_dec_self_attn(hipStream_t s, int prec, const void* qkv, void* kc, void* vc, void* out, const int* pos_p,
                              int d, int n_heads, int tc, int B, int mpad) {
     dim3 grid(n_heads, B);
-    if (prec == WH_PREC_F32 || prec == WH_PREC_F16X3)
+    if (prec == WH_PREC_F16X3)   // f32 q/k/v and caches (no matrix-core work here), the output as the out-projection's fp16-limb operand
+        hipLaunchKernelGGL((k_dec_self_attn<float, h2>), grid, dim3(64), 0, s, (const float*)qkv, (float*)kc, (float*)vc, (h2*)out, pos_p, d, n_heads, tc, mpad);
+    else if (prec == WH_PREC_F32)
         hipLaunchKernelGGL(k_dec_self_attn<float>, grid, dim3(64), 0, s, (const float*)qkv, (float*)kc, (float*)vc, (float*)out, pos_p, d, n_heads, tc, mpad);
     else
         hipLaunchKernelGGL(k_dec_self_attn<bf16>, grid, dim3(64), 0, s, (const bf16*)qkv, (bf16*)kc, (bf16*)vc, (bf16*)out, pos_p, d, n_heads, tc, mpad);
@@ -1395,13 +1409,21 @@ void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void
     const bool f32_layout = prec == WH_PREC_F32 || prec == WH_PREC_F16X3;   // (no matrix-core work in this kernel: the f32 form serves both)
     const long wgs = (long)splits * B * ((!f32_layout && d > 512 && d % 256 == 0) ? d / 256 : 1);
     const size_t sm = wh_cross_lds_reserve(wgs, sizeof(float) * ((size_t)8 * n_heads + 4 * (size_t)d));
-#define WH_CA1(T_, N_, U_, NT_) do { set_max_smem(k_dec_cross_attn<T_, N_, U_, NT_>, sm);                                                 \
-                                     hipLaunchKernelGGL((k_dec_cross_attn<T_, N_, U_, NT_>), grid, dim3(256), sm, s, (const T_*)q, (const T_*)ck, \
-                                             (const T_*)cv, part, ml, S, d, n_heads, splits, (T_*)(splits == 1 ? out : nullptr), mpad); } while (0)
+#define WH_CA2(T_, N_, U_, NT_, TO_) do { set_max_smem(k_dec_cross_attn<T_, N_, U_, NT_, TO_>, sm);                                                 \
+                                     hipLaunchKernelGGL((k_dec_cross_attn<T_, N_, U_, NT_, TO_>), grid, dim3(256), sm, s, (const T_*)q, (const T_*)ck, \
+                                             (const T_*)cv, part, ml, S, d, n_heads, splits, (TO_*)(splits == 1 ? out : nullptr), mpad); } while (0)
+#define WH_CA1(T_, N_, U_, NT_) WH_CA2(T_, N_, U_, NT_, T_)
     static const int nt_env = [] { const char* e = getenv("WH_CROSS_NT"); return e ? atoi(e) : -1; }();   // (A/B runs: force the non-temporal K/V loads off / on)
     if (nt_env >= 0) stream_nt = nt_env != 0;
 #define WH_CA(T_, N_, U_) do { if (stream_nt) WH_CA1(T_, N_, U_, true); else WH_CA1(T_, N_, U_, false); } while (0)
-    if (f32_layout) {
+    if (prec == WH_PREC_F16X3) {   // the f32 kernel (no matrix-core work); one key range per clip writes the out-projection's fp16-limb operand
+#define WH_CAX(N_, U_) do { if (stream_nt) WH_CA2(float, N_, U_, true, h2); else WH_CA2(float, N_, U_, false, h2); } while (0)
+        const int nch = (d / 4 + 63) / 64;
+        if (nch == 1) WH_CAX(1, 4);
+        else if (nch == 2) WH_CAX(2, 2);
+        else WH_CAX(5, 1);
+#undef WH_CAX
+    } else if (f32_layout) {
         const int nch = (d / 4 + 63) / 64;  // f32: 4 elements per chunk
         if (nch == 1) WH_CA(float, 1, 4);
         else if (nch == 2) WH_CA(float, 2, 2);
@@ -1425,4 +1447,5 @@ void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void
     }
 #undef WH_CA
 #undef WH_CA1
+#undef WH_CA2
 }

@@ -418,9 +418,24 @@ void quantize_rows(const float* W, size_t rows, size_t cols, float rscale, QRows
     }
 }
 
+// f32 -> fp16 limbs exactly as the device does (wh_common.h x3_split: hi = f16(x) RNE, lo = f16(x - hi))
+static inline void f32_to_h2(float x, uint16_t* hi, uint16_t* lo) {
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    memcpy(hi, &h, 2);
+    memcpy(lo, &l, 2);
+}
+static inline float h2_value(float x) {   // the value an h2 element holds for x
+    const _Float16 h = (_Float16)x;
+    return (float)h + (float)(_Float16)(x - (float)h);
+}
+
 struct Stager {
     std::vector<char> host;
     size_t esz;
+    // WH_PREC_F16X3, matrices read as `h2` operands (wh_common.h): rows as 128-byte blocks [32 x fp16 hi | 32 x fp16 lo] per 32
+    // columns (cols_pad a multiple of 32) — 4 bytes per element like f32, so sizes and offsets are the f32 ones
+    bool planar = false;
     explicit Stager(size_t e) : esz(e) {}
     size_t reserve(size_t bytes) {
         size_t off = (host.size() + 255) & ~(size_t)255;
@@ -434,7 +449,10 @@ struct Stager {
         return off;
     }
     void put_row(size_t off, size_t r, size_t cols_pad, const float* src, size_t cols, float scale) {
-        if (esz == 4) {
+        if (planar) {
+            uint16_t* d = (uint16_t*)(host.data() + off) + r * cols_pad * 2;
+            for (size_t c = 0; c < cols; c++) f32_to_h2(src[c] * scale, d + (c >> 5) * 64 + (c & 31), d + (c >> 5) * 64 + 32 + (c & 31));
+        } else if (esz == 4) {
             float* d = (float*)(host.data() + off) + r * cols_pad;
             for (size_t c = 0; c < cols; c++) d[c] = src[c] * scale;
         } else {
@@ -584,7 +602,12 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
         x.l2b = st.put_f32(T(p + ".final_layer_norm.bias"), d);
     }
     size_t o_elnw = st.put_f32(T(e + ".layer_norm.weight"), d), o_elnb = st.put_f32(T(e + ".layer_norm.bias"), d);
+    // WH_PREC_F16X3: everything the decoder's matrix-core kernels read is stored as fp16 limbs (`h2`); the encoder side and the stacked
+    // cross-K/V projection keep f32 rows (split at the fragment loads)
+    const bool x3 = precision == WH_PREC_F16X3;
+    st.planar = x3;
     size_t o_tok = st.put_mat(T(dd + ".embed_tokens.weight"), c.vocab, d, d);
+    st.planar = false;
     size_t o_dpos = st.put_f32(T(dd + ".embed_positions.weight"), (size_t)c.n_text_ctx * d);
     struct DecOff { size_t qkv, qkvb, qkvs, o, ob, cq, cqb, cqs, co, cob, f1, f1b, f1s, f2, f2b, l1w, l1b, l2w, l2b, l3w, l3b,
                            qkvsc, osc, cqsc, cosc, f1sc, f2sc; };
@@ -618,7 +641,7 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
             for (size_t k = 0; k < cols; k++) {
                 const float w = W[r * cols + k] * rscale;
                 row[k] = w * gamma[k];
-                sacc += (m->esz == 2) ? (double)bf16_to_f32(f32_to_bf16(row[k])) : (double)row[k];
+                sacc += (m->esz == 2) ? (double)bf16_to_f32(f32_to_bf16(row[k])) : st.planar ? (double)h2_value(row[k]) : (double)row[k];
                 cacc += (double)beta[k] * (double)w;
             }
             st.put_row(off, row0 + r, cols, row.data(), cols, 1.0f);
@@ -656,6 +679,7 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     std::vector<DecOff> dof(c.dec_layers);
     const size_t Ld = c.dec_layers;
     size_t o_ckv = st.reserve(Ld * 2 * d * d * m->esz);
+    st.planar = x3;
     tmp.assign(Ld * 2 * d, 0.0f);
     std::vector<float> ckvb(Ld * 2 * d, 0.0f);
     std::vector<float> ckvsc(Ld * 2 * d, 1.0f);
@@ -724,11 +748,13 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
         x.cqb = st.put_f32(c1.data(), d);
         x.cqs = st.put_f32(s1.data(), d);
         x.co = st.put_mat(T(p + ".encoder_attn.out_proj.weight"), d, d, d);
+        st.planar = false;   // (read by the encoder-side GEMM: f32 rows)
         for (size_t r = 0; r < d; r++) {
             st.put_row(o_ckv, ((size_t)i * 2 + 0) * d + r, d, T(p + ".encoder_attn.k_proj.weight") + r * d, d, 1.0f);
             st.put_row(o_ckv, ((size_t)i * 2 + 1) * d + r, d, T(p + ".encoder_attn.v_proj.weight") + r * d, d, 1.0f);
             ckvb[((size_t)i * 2 + 1) * d + r] = T(p + ".encoder_attn.v_proj.bias")[r];
         }
+        st.planar = x3;
         x.f1 = st.reserve(F * d * m->esz);
         fold_ln(x.f1, 0, T(p + ".fc1.weight"), F, d, 1.0f, T(p + ".final_layer_norm.weight"), T(p + ".final_layer_norm.bias"),
                 T(p + ".fc1.bias"), s1.data(), c1.data());
@@ -752,6 +778,7 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     //   out[64 h + t] = sum_j Wv[64 h + t][j] ctx[h][j] + bv[64 h + t]   (grouped decode GEMM) -> the plain W_v rows and b_v of the stacked
     //   cross-K/V projection (cross_kv_w / cross_kv_b), which stay on the device for the contexts that project K and V
     // The query projection (LN2 folded, pre-scaled) and the out-projection are the ones the K / V form uses.
+    st.planar = false;
     std::vector<size_t> o_cqx(c.dec_layers, NONE);
     const bool cross_es = m->prec == WH_PREC_BF16 && wh_cross_es_geometry(c.d_model, c.n_heads, c.n_audio_ctx);
     if (cross_es) {
@@ -800,9 +827,11 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
             lmc[n] = (float)cacc;
         }
     } else {
+        st.planar = x3;
         o_lmw = st.reserve((size_t)c.vocab * d * m->esz);
         fold_ln(o_lmw, 0, T(dd + ".embed_tokens.weight"), c.vocab, d, 1.0f, T(dd + ".layer_norm.weight"), T(dd + ".layer_norm.bias"), nullptr,
                 lms.data(), lmc.data());
+        st.planar = false;
     }
     size_t o_lms = st.put_f32(lms.data(), c.vocab), o_lmc = st.put_f32(lmc.data(), c.vocab);
     // log-mel tables
