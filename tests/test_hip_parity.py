@@ -636,6 +636,11 @@ def test_cross_mode_rule_and_flags(gpu):
     c = wb.Context(base32, 256)
     assert c.cross_mode == 0        # the exact-f32 mode keeps the reference's K / V form
     c.close()
+    basex3 = wb.Model("synthetic:base:1234", 0, wb.WH_PREC_F16X3)
+    for mb, want in ((64, 0), (256, 1)):   # the split-fp16 mode streams the states as fp16 limb planes (k_dec_cross_attn_es2)
+        c = wb.Context(basex3, mb)
+        assert c.cross_mode == want, (mb, c.cross_mode)
+        c.close()
 
 
 @pytest.mark.parametrize("nb", [32, 288])

@@ -132,6 +132,7 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
         g.W = m->conv1_w; g.ldw = m->conv1_k;
         g.C = (char*)c->h1 + d * esz; g.ldc = d; g.c_bs = (long)H1_ROWS * d;
         g.bias = m->conv1_b; g.bias_mode = 1; g.act = 1;
+        g.f32_operands = true;   // (WH_PREC_F16X3: the only GEMM whose operands stay f32 rows, see GemmArgs)
         g.M = nb * WH_N_FRAMES; g.N = (int)d; g.K = m->conv1_k;
         CTX_LAUNCH(c, wh_launch_gemm(s, prec, false, g));
     }
@@ -244,7 +245,7 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
         if (c->mx_ok) CTX_LAUNCH(c, wh_launch_layernorm_mx(s, c->x, m->enc_ln_w, m->enc_ln_b, c->xn8, c->xn8_sc, rows, (int)d));
         else if (!fold) wh_launch_layernorm(s, prec, c->x, m->enc_ln_w, m->enc_ln_b, c->enc_out, rows, (int)d);
         if (want_f32) {
-            if (esz == 4) hipMemcpyAsync(c->enc_out_f32, c->enc_out, rows * d * 4, hipMemcpyDeviceToDevice, s);
+            if (prec == WH_PREC_F32) hipMemcpyAsync(c->enc_out_f32, c->enc_out, rows * d * 4, hipMemcpyDeviceToDevice, s);
             else wh_launch_layernorm(s, WH_PREC_F32, c->x, m->enc_ln_w, m->enc_ln_b, c->enc_out_f32, rows, (int)d);
         }
     }
@@ -343,7 +344,8 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
         // no projection: the token loop attends over the encoder states themselves (wh_cross_es.hip).  Their final LayerNorm runs
         // here, on the decode stream, into decode-side storage — the encoder-side workspace is free for the next pass afterwards
         Prof pr(c, WH_KG_DEC_GEMM);
-        wh_launch_layernorm_blocks(s, prec, c->x, m->enc_ln_w, m->enc_ln_b, c->es_E, (long)nb * S, (int)d, c->es_rows == (int)S ? 0 : (int)S, c->es_rows);
+        if (prec == WH_PREC_F16X3) wh_launch_layernorm_es2(s, c->x, m->enc_ln_w, m->enc_ln_b, c->es_E, (long)nb * S, (int)S, c->es_rows);   // fp16 limb planes
+        else wh_launch_layernorm_blocks(s, prec, c->x, m->enc_ln_w, m->enc_ln_b, c->es_E, (long)nb * S, (int)d, c->es_rows == (int)S ? 0 : (int)S, c->es_rows);
     } else {
         Prof pr(c, WH_KG_DEC_GEMM);
         GemmArgs g;
@@ -356,7 +358,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
             g.A = c->xb; g.W = m->cross_kv_wf; g.bias = m->cross_kv_c; g.ln_mode = 1; g.ln_stat = c->enc_stat; g.ln_s = m->cross_kv_s;
         }
         if (c->mx_ok) { g.A = c->xn8; g.a_sc = c->xn8_sc; g.W = m->cross_kv_w8; CTX_LAUNCH(c, wh_launch_gemm8_mx(s, 0, g)); }   // xn8 = MX(final LN), run_encoder
-        else CTX_LAUNCH(c, wh_launch_gemm(s, prec, false, g));
+        else CTX_LAUNCH(c, wh_launch_gemm(s, prec, prec == WH_PREC_F16X3, g));   // (split-fp16 mode: K and V as f32 rows — their consumer is the f32 attention kernel, no matrix-core operand)
         if (f8) {  // bf16 projection → e4m3 codes, one scale per (layer, K|V, clip, head)
             const long planes = (long)D.dec_layers * 2 * nb;
             CTX_HIP(c, hipMemsetAsync(c->kv_amax, 0, planes * D.n_heads * 4, s));
@@ -426,11 +428,11 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                     a.ln_part = c->lnpart; a.ln_tiles = ln_tiles_d; a.ln_s = L.cq_s;
                     wh_launch_dec_gemm(s, prec, true, a);
                     // expanded queries qe[h] = W_k,h^T q_h: [nb][H][d] f32
-                    wh_launch_dec_qexpand(s, c->dq32, L.cqx_w, c->dqe, nb, (int)d, D.n_heads);
+                    wh_launch_dec_qexpand(s, prec, c->dq32, L.cqx_w, c->dqe, nb, (int)d, D.n_heads);
                 }
                 {
                     Prof pr(c, WH_KG_DEC_CROSS_ATTN);
-                    wh_launch_dec_cross_attn_es(s, c->dqe, c->es_E, c->dctx, (int)S, c->es_rows, nb, mpad, kv_nt);
+                    wh_launch_dec_cross_attn_es(s, prec, c->dqe, c->es_E, c->dctx, (int)S, c->es_rows, nb, mpad, kv_nt);
                 }
                 {   // per head: W_v,h ctx_h + b_v,h → the attention output the out-projection below expects (slab layout)
                     Prof pr(c, WH_KG_DEC_GEMM);
@@ -816,7 +818,7 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     if (const char* e = getenv("WH_CROSS_ES")) c->cross_es = m->cross_es && atoi(e) != 0;
     if ((opts->flags & WH_CTX_CROSS_ES_ON) && !m->cross_es) {
         delete c;
-        wh_set_error("wh_ctx_create_ex: WH_CTX_CROSS_ES_ON needs a bf16 model of whisper-base geometry (d_model 512, 8 heads)");
+        wh_set_error("wh_ctx_create_ex: WH_CTX_CROSS_ES_ON needs a bf16 or f16x3 model of whisper-base geometry (d_model 512, 8 heads)");
         return WH_ERR_UNSUPPORTED;
     }
     // rows from one clip's encoder states to the next: 20 rows (20 KiB) of padding, so that the lock-step streams of the persistent

@@ -29,6 +29,7 @@ template <typename T> struct HalfFrag;  // 4 consecutive elements
 template <> struct HalfFrag<bf16> { typedef bf16x4 type; };
 template <> struct HalfFrag<float> { typedef f32x4 type; };
 template <> struct HalfFrag<xf32> { typedef f32x4 type; };
+template <> struct HalfFrag<h2> { typedef f32x4 type; };   // (unused: h2 rows are read limb-wise, see vt_frag)
 
 __device__ __forceinline__ bf16x8 join_half(bf16x4 a, bf16x4 b) { return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 __device__ __forceinline__ f32x8 join_half(f32x4 a, f32x4 b) { return f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
@@ -44,21 +45,39 @@ template <typename T> struct Joiner {
 template <> struct Joiner<xf32> {
     static __device__ __forceinline__ xfrag join(f32x4 a, f32x4 b) { return x3_split(join_half(a, b)); }
 };
+// V^T row operand of contraction step ks: k-slots 8 fg + j <-> keys 32 ks + 4 fg + j (j < 4) and 32 ks + 16 + 4 fg + j - 4 (j >= 4) of the 64-key tile
+template <typename T>
+__device__ __forceinline__ typename FragT<T>::type vt_frag(const T* row, int ks, int fg) {
+    typedef typename HalfFrag<T>::type half_t;
+    const T* vp = row + 32 * ks + 4 * fg;
+    return Joiner<T>::join(*reinterpret_cast<const half_t*>(vp), *reinterpret_cast<const half_t*>(vp + 16));
+}
+template <>
+__device__ __forceinline__ xfrag vt_frag<h2>(const h2* row, int ks, int fg) {   // 4 consecutive keys = 8 bytes of hi limbs + 8 bytes of lo limbs of the 32-key block
+    const char* b = reinterpret_cast<const char*>(row) + 128 * ks + 8 * fg;
+    const f16x4 h0 = *reinterpret_cast<const f16x4*>(b), h1 = *reinterpret_cast<const f16x4*>(b + 32);
+    const f16x4 l0 = *reinterpret_cast<const f16x4*>(b + 64), l1 = *reinterpret_cast<const f16x4*>(b + 96);
+    xfrag r;
+    r.hi = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    r.lo = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+    return r;
+}
 
 template <typename T, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void k_enc_attn(const T* __restrict__ qk, const T* __restrict__ vT,
                                                           T* __restrict__ out, int S, int d, int ldv, int n_heads) {
     constexpr int HD = WH_HEAD_DIM, KV = 64, QB = NWAVES * 32, NT_ = NWAVES * 64;
-    constexpr int LD = HD + 16 / (int)sizeof(T);  // padded LDS row of the K tile (elements): +16 B, conflict-free for 16-B reads
+    // padded LDS row of the K tile (elements): +16 B, conflict-free for 16-B reads; h2 rows (two 128-byte blocks: hi and lo chunks 64 bytes
+    // apart) take +32 B: 72 dwords per row put the 16 rows of a fragment read on 16 distinct 4-bank groups
+    constexpr int LD = __is_same(T, h2) ? HD + 8 : HD + 16 / (int)sizeof(T);
     // V^T tile: read 8 bytes per lane (bf16), 16 lanes per LDS cycle — rows 144 B apart put lanes fl and fl+8 on the
     // same banks (2-way conflict on every read); 136-B rows spread the 16 lanes over all 32 banks.  Its staging
     // stores are then 8-byte ones (rows are only 8-byte aligned).
-    constexpr int LDV = sizeof(T) == 2 ? HD + 4 : LD;
+    constexpr int LDV = (sizeof(T) == 2 || __is_same(T, h2)) ? HD + 4 : LD;   // (h2: 8-byte limb reads like bf16's — 68-dword rows spread 16 rows x 2 groups over all 64 banks)
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int CPR = HD / EPC;                 // 16-B chunks per 64-element row
     constexpr int NCH = KV * CPR / NT_;           // staging chunks per thread per operand: 2 (bf16) / 4 (f32) with 4 waves, half with 8
     typedef typename FragT<T>::type frag_t;
-    typedef typename HalfFrag<T>::type half_t;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* Ks = reinterpret_cast<T*>(smem_raw);       // [2][KV][LD]   rows = keys
@@ -154,8 +173,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_enc_attn(const T* __restrict__ 
         f32x4 sc[2][4];
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const frag_t k0f = load_frag<T>(&Kc[(t * 16 + fl) * LD + fg * 8]);
-            const frag_t k1f = load_frag<T>(&Kc[(t * 16 + fl) * LD + 32 + fg * 8]);
+            const frag_t k0f = slab_frag<T>(&Kc[(t * 16 + fl) * LD], fg);
+            const frag_t k1f = slab_frag<T>(&Kc[(t * 16 + fl) * LD + 32], fg);
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 sc[u][t] = f32x4{0, 0, 0, 0};
@@ -219,8 +238,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_enc_attn(const T* __restrict__ 
         for (int te = 0; te < 4; te++) {
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
-                const T* vp = &Vc[(te * 16 + fl) * LDV + 32 * ks + 4 * fg];
-                const frag_t vf = Joiner<T>::join(*reinterpret_cast<const half_t*>(vp), *reinterpret_cast<const half_t*>(vp + 16));
+                const frag_t vf = vt_frag<T>(&Vc[(te * 16 + fl) * LDV], ks, fg);
                 mma16(o[0][te], vf, pf[0][ks]);
                 mma16(o[1][te], vf, pf[1][ks]);
             }
@@ -254,11 +272,11 @@ void wh_launch_enc_attn(hipStream_t s, int prec, const void* qk, const void* vT,
         const size_t sm = (size_t)2 * 2 * 64 * (64 + 4) * 4;  // 69.6 KB: above the default dynamic-LDS limit
         wh_ensure_dyn_lds((const void*)k_enc_attn<float, 4>, sm);
         hipLaunchKernelGGL((k_enc_attn<float, 4>), grid, dim3(256), sm, s, (const float*)qk, (const float*)vT, (float*)out, S, d, ldv, n_heads);
-    } else if (prec == WH_PREC_F16X3) {   // f32 tiles, fp16 limbs at the fragment loads
+    } else if (prec == WH_PREC_F16X3) {   // Q, K, V^T and the output as fp16 limb pairs (h2); the probabilities are split in registers
         dim3 grid(((S + 127) / 128) * n_heads * n_clips);
-        const size_t sm = (size_t)2 * 2 * 64 * (64 + 4) * 4;
-        wh_ensure_dyn_lds((const void*)k_enc_attn<xf32, 4>, sm);
-        hipLaunchKernelGGL((k_enc_attn<xf32, 4>), grid, dim3(256), sm, s, (const xf32*)qk, (const xf32*)vT, (xf32*)out, S, d, ldv, n_heads);
+        const size_t sm = (size_t)2 * 2 * 64 * (64 + 8) * 4;
+        wh_ensure_dyn_lds((const void*)k_enc_attn<h2, 4>, sm);
+        hipLaunchKernelGGL((k_enc_attn<h2, 4>), grid, dim3(256), sm, s, (const h2*)qk, (const h2*)vT, (h2*)out, S, d, ldv, n_heads);
     } else {
         const size_t sm = (size_t)2 * 2 * 64 * (64 + 8) * 2;
         // 8 waves = 256 query rows per workgroup: each K / V^T tile is staged once per 256 queries instead of once per 128

@@ -129,6 +129,28 @@ __device__ __forceinline__ void store4(h2* p, float a, float b, float c, float d
     *reinterpret_cast<f16x4*>(q) = hi;
     *reinterpret_cast<f16x4*>(q + 64) = lo;
 }
+__device__ __forceinline__ void store8(float* p, const f32x8& v) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+// fragment of k-group fg (8 consecutive k) of the 32-deep slab that starts at `slab` — for LDS tiles whose rows are not 128-byte
+// aligned (padded pitches), where an h2 block cannot be found from the element address: the slab start is given instead
+template <typename T>
+__device__ __forceinline__ typename FragT<T>::type slab_frag(const T* slab, int fg) { return load_frag<T>(slab + 8 * fg); }
+template <>
+__device__ __forceinline__ xfrag slab_frag<h2>(const h2* slab, int fg) {
+    const char* b = reinterpret_cast<const char*>(slab) + 16 * fg;
+    xfrag r;
+    r.hi = *reinterpret_cast<const f16x8*>(b);
+    r.lo = *reinterpret_cast<const f16x8*>(b + 64);
+    return r;
+}
+__device__ __forceinline__ void store8(h2* p, const f32x8& v) {   // 8 consecutive elements: two 16-byte stores
+    char* q = const_cast<char*>(h2_limb(p));
+    const xfrag f = x3_split(v);
+    *reinterpret_cast<f16x8*>(q) = f.hi;
+    *reinterpret_cast<f16x8*>(q + 64) = f.lo;
+}
 __device__ __forceinline__ void store1(h2* p, float v) {
     char* q = const_cast<char*>(h2_limb(p));
     const _Float16 hi = (_Float16)v;

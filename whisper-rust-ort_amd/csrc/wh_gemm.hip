@@ -28,6 +28,7 @@ template <typename T> struct Tile;  // K-step depth and LDS row stride (elements
 template <> struct Tile<bf16> { static constexpr int BK = 64, LDK = 72; };   // 144 B rows
 template <> struct Tile<float> { static constexpr int BK = 32, LDK = 36; };  // 144 B rows
 template <> struct Tile<xf32> { static constexpr int BK = 32, LDK = 36; };   // WH_PREC_F16X3: f32 tiles, split into fp16 limbs at the fragment load
+template <> struct Tile<h2> { static constexpr int BK = 32, LDK = 36; };     // ... or already split: one 128-byte block [hi | lo] per row and k-step
 
 template <typename T, typename TO, int BM, int BN>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
@@ -127,9 +128,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         for (int ks = 0; ks < BK / 32; ks++) {
             typename FragT<T>::type af[TM], wf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; i++) af[i] = load_frag<T>(&Ac[(wr * (BM / 2) + i * 16 + fl) * LDK + ks * 32 + fg * 8]);
+            for (int i = 0; i < TM; i++) af[i] = slab_frag<T>(&Ac[(wr * (BM / 2) + i * 16 + fl) * LDK + ks * 32], fg);
 #pragma unroll
-            for (int j = 0; j < TN; j++) wf[j] = load_frag<T>(&Wc[(wc * (BN / 2) + j * 16 + fl) * LDK + ks * 32 + fg * 8]);
+            for (int j = 0; j < TN; j++) wf[j] = slab_frag<T>(&Wc[(wc * (BN / 2) + j * 16 + fl) * LDK + ks * 32], fg);
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -342,6 +343,7 @@ bool wh_gemm8_enabled() {
 
 int wh_launch_gemm(hipStream_t s, int prec, bool out_f32, const GemmArgs& g) {
     if (prec != WH_PREC_F32 && prec != WH_PREC_F16X3 && wh_gemm8_enabled() && !g.small_ctx && wh_gemm8_applicable(g)) return wh_launch_gemm8(s, out_f32, g);
+    if (prec == WH_PREC_F16X3 && !g.f32_operands && wh_gemm8_enabled() && !g.small_ctx && wh_gemm8x_applicable(g, !out_f32)) return wh_launch_gemm8x(s, !out_f32, g);
     if (g.ln_mode || g.xb_out || g.stats_out) {   // only k_gemm8 implements the LayerNorm fold: never drop it silently
         wh_set_error("GEMM with a folded LayerNorm (M %d N %d K %d) must run on k_gemm8", g.M, g.N, g.K);
         return WH_ERR_UNSUPPORTED;
@@ -353,8 +355,10 @@ int wh_launch_gemm(hipStream_t s, int prec, bool out_f32, const GemmArgs& g) {
     }
     if (prec == WH_PREC_F32) {
         launch_gemm_t<float, float>(s, g);
-    } else if (prec == WH_PREC_F16X3) {
-        launch_gemm_t<xf32, float>(s, g);
+    } else if (prec == WH_PREC_F16X3) {   // results: f32 rows (residual stream, f32 consumers) or h2 (the next matrix-core consumer's operand)
+        if (g.f32_operands) { if (out_f32) launch_gemm_t<xf32, float>(s, g); else launch_gemm_t<xf32, h2>(s, g); }
+        else if (out_f32) launch_gemm_t<h2, float>(s, g);
+        else launch_gemm_t<h2, h2>(s, g);
     } else {
         if (out_f32) launch_gemm_t<bf16, float>(s, g);
         else launch_gemm_t<bf16, bf16>(s, g);
@@ -372,7 +376,8 @@ void wh_launch_layernorm_blocks(hipStream_t s, int prec, const float* x, const f
         else hipLaunchKernelGGL(k_layernorm_w8<2>, g8, dim3(256), 0, s, x, w, b, (bf16*)y, rows, d, in_blk, out_blk);
         return;
     }
-    if (f32_layout) hipLaunchKernelGGL(k_layernorm<float>, grid, dim3(256), 0, s, x, w, b, (float*)y, rows, d, in_blk, out_blk);
+    if (prec == WH_PREC_F16X3) hipLaunchKernelGGL(k_layernorm<h2>, grid, dim3(256), 0, s, x, w, b, (h2*)y, rows, d, in_blk, out_blk);   // the consumers' fp16-limb operand
+    else if (f32_layout) hipLaunchKernelGGL(k_layernorm<float>, grid, dim3(256), 0, s, x, w, b, (float*)y, rows, d, in_blk, out_blk);
     else hipLaunchKernelGGL(k_layernorm<bf16>, grid, dim3(256), 0, s, x, w, b, (bf16*)y, rows, d, in_blk, out_blk);
 }
 

@@ -302,7 +302,6 @@ __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs
 #pragma unroll
         for (int ii = 0; ii < 2; ii++) {
             const int i = pass * 2 + ii;
-            const int m = mw0 + i * 16 + fl;
             const float bm = rowb[i], wmul = rowa[i];   // LN 1: bm = rstd[m], wmul = mean[m];  LN 2: bm = c[m], wmul = s[m]
 #pragma unroll
             for (int j = 0; j < TN; j++) {

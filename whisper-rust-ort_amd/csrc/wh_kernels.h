@@ -28,6 +28,9 @@ struct GemmArgs {
     // 128 x 128 kernel runs instead (1 clip: 0.57 vs 1.17 ms of encoder GEMMs, 4 clips: 0.93 vs 1.33, 16 clips: 2.48 vs 2.19).
     // Chosen from the context's capacity, never from the call's clip count: a clip decodes identically alone or in a batch.
     bool small_ctx = false;
+    // WH_PREC_F16X3: operands are fp16 limb pairs (h2) unless this is set — f32 rows split at the fragment loads (conv1, whose overlapping
+    // rows of the token-major log-mel start at multiples of n_mels elements, not of the 32-element h2 block)
+    bool f32_operands = false;
     // wh_gemm8_mx.hip (WH_PREC_FP8): A and W hold e4m3 codes (one byte per element; lda, ldw, a_bs, *_zs in elements = bytes)
     // with E8M0 block exponents per (row, 32 consecutive k), layout [row][4][wh_mx_nkp(K)]; null = no block exponents (weights)
     const unsigned char* a_sc = nullptr;
@@ -142,6 +145,9 @@ bool wh_gemm8_applicable(const GemmArgs& g);
 // {mean, rstd} per row from the producers' partial sums: stat[row][2] <- partials[groups][rows][2] (groups added in order)
 void wh_launch_ln_stats(hipStream_t s, const float* partials, int groups, long rows, int d, float* stat);
 int wh_launch_gemm8(hipStream_t s, bool out_f32, const GemmArgs& g);
+// wh_gemm8x.hip: WH_PREC_F16X3 on 256 x 256 LDS-DMA tiles, h2 operands, f32 or h2 results
+bool wh_gemm8x_applicable(const GemmArgs& g, bool out_h2);
+int wh_launch_gemm8x(hipStream_t s, bool out_h2, const GemmArgs& g);
 // MX block exponents of a [rows][K] operand: [row][4][nkp] bytes, nkp = K-steps of 128 rounded up to a multiple of 4 (from 4 on)
 // so that the bytes of 16 consecutive K-steps are four aligned dwords
 __host__ __device__ inline int wh_mx_nkp(int K) { const int nk = K >> 7; return nk < 4 ? nk : (nk + 3) / 4 * 4; }
@@ -182,8 +188,10 @@ void wh_launch_dec_cross_attn(hipStream_t s, int prec, const void* q, const void
 bool wh_cross_es_geometry(int d, int n_heads, int S);
 // expanded queries qe[m][h][j] = sum_t q[m][64 h + t] * wkT[h][j][t]: q [M][d] f32 (pre-scaled, bias included), wkT [H][d][64] bf16
 // (head h's rows of W_k, transposed), qe [M][H][d] f32.  q enters the bf16 MFMAs as hi + lo, so nothing of it is rounded.
-void wh_launch_dec_qexpand(hipStream_t s, const float* q, const void* wkT, float* qe, int M, int d, int n_heads);
-void wh_launch_dec_cross_attn_es(hipStream_t s, const float* qe, const void* E, void* out, int S, int e_rows, int B, int mpad, bool stream_nt);   // e_rows >= S: rows between two clips' states
+// (WH_PREC_F16X3: wkT as h2, E as fp16 limb planes [B][e_rows][hi d | lo d] written by wh_launch_layernorm_es2, out as an h2 slab)
+void wh_launch_dec_qexpand(hipStream_t s, int prec, const float* q, const void* wkT, float* qe, int M, int d, int n_heads);
+void wh_launch_dec_cross_attn_es(hipStream_t s, int prec, const float* qe, const void* E, void* out, int S, int e_rows, int B, int mpad, bool stream_nt);   // e_rows >= S: rows between two clips' states
+void wh_launch_layernorm_es2(hipStream_t s, const float* x, const float* w, const float* b, void* y, long rows, int in_blk, int out_blk);
 
 // dynamic LDS to request for a cross-attention launch of total_wgs workgroups whose kernel needs own_bytes: caps the resident
 // workgroups per CU at two for large launches (wh_decode.hip)

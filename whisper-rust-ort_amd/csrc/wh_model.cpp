@@ -551,7 +551,11 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     };
     m->conv1_k = (int)((3 * C + 31) / 32 * 32);
     const std::string e = "model.encoder", dd = "model.decoder";
+    // WH_PREC_F16X3: every matrix a matrix-core kernel reads is stored as fp16 limb pairs (`h2`, wh_common.h) — except conv1, whose
+    // activation rows (overlapping windows of the token-major log-mel) cannot be h2 blocks: f32 rows, split at the fragment loads
+    const bool x3 = precision == WH_PREC_F16X3;
     size_t o_conv1 = conv_reorder(T(e + ".conv1.weight"), d, C, m->conv1_k);
+    st.planar = x3;
     size_t o_conv1b = st.put_f32(T(e + ".conv1.bias"), d);
     size_t o_conv2 = conv_reorder(T(e + ".conv2.weight"), d, d, 3 * d);
     size_t o_conv2b = st.put_f32(T(e + ".conv2.bias"), d);
@@ -602,12 +606,7 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
         x.l2b = st.put_f32(T(p + ".final_layer_norm.bias"), d);
     }
     size_t o_elnw = st.put_f32(T(e + ".layer_norm.weight"), d), o_elnb = st.put_f32(T(e + ".layer_norm.bias"), d);
-    // WH_PREC_F16X3: everything the decoder's matrix-core kernels read is stored as fp16 limbs (`h2`); the encoder side and the stacked
-    // cross-K/V projection keep f32 rows (split at the fragment loads)
-    const bool x3 = precision == WH_PREC_F16X3;
-    st.planar = x3;
     size_t o_tok = st.put_mat(T(dd + ".embed_tokens.weight"), c.vocab, d, d);
-    st.planar = false;
     size_t o_dpos = st.put_f32(T(dd + ".embed_positions.weight"), (size_t)c.n_text_ctx * d);
     struct DecOff { size_t qkv, qkvb, qkvs, o, ob, cq, cqb, cqs, co, cob, f1, f1b, f1s, f2, f2b, l1w, l1b, l2w, l2b, l3w, l3b,
                            qkvsc, osc, cqsc, cosc, f1sc, f2sc; };
@@ -679,7 +678,6 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     std::vector<DecOff> dof(c.dec_layers);
     const size_t Ld = c.dec_layers;
     size_t o_ckv = st.reserve(Ld * 2 * d * d * m->esz);
-    st.planar = x3;
     tmp.assign(Ld * 2 * d, 0.0f);
     std::vector<float> ckvb(Ld * 2 * d, 0.0f);
     std::vector<float> ckvsc(Ld * 2 * d, 1.0f);
@@ -748,13 +746,11 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
         x.cqb = st.put_f32(c1.data(), d);
         x.cqs = st.put_f32(s1.data(), d);
         x.co = st.put_mat(T(p + ".encoder_attn.out_proj.weight"), d, d, d);
-        st.planar = false;   // (read by the encoder-side GEMM: f32 rows)
         for (size_t r = 0; r < d; r++) {
             st.put_row(o_ckv, ((size_t)i * 2 + 0) * d + r, d, T(p + ".encoder_attn.k_proj.weight") + r * d, d, 1.0f);
             st.put_row(o_ckv, ((size_t)i * 2 + 1) * d + r, d, T(p + ".encoder_attn.v_proj.weight") + r * d, d, 1.0f);
             ckvb[((size_t)i * 2 + 1) * d + r] = T(p + ".encoder_attn.v_proj.bias")[r];
         }
-        st.planar = x3;
         x.f1 = st.reserve(F * d * m->esz);
         fold_ln(x.f1, 0, T(p + ".fc1.weight"), F, d, 1.0f, T(p + ".final_layer_norm.weight"), T(p + ".final_layer_norm.bias"),
                 T(p + ".fc1.bias"), s1.data(), c1.data());
@@ -778,9 +774,9 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     //   out[64 h + t] = sum_j Wv[64 h + t][j] ctx[h][j] + bv[64 h + t]   (grouped decode GEMM) -> the plain W_v rows and b_v of the stacked
     //   cross-K/V projection (cross_kv_w / cross_kv_b), which stay on the device for the contexts that project K and V
     // The query projection (LN2 folded, pre-scaled) and the out-projection are the ones the K / V form uses.
-    st.planar = false;
     std::vector<size_t> o_cqx(c.dec_layers, NONE);
-    const bool cross_es = m->prec == WH_PREC_BF16 && wh_cross_es_geometry(c.d_model, c.n_heads, c.n_audio_ctx);
+    // (WH_PREC_F16X3: the same, with both matrices as fp16 limbs)
+    const bool cross_es = (m->prec == WH_PREC_BF16 || x3) && wh_cross_es_geometry(c.d_model, c.n_heads, c.n_audio_ctx);
     if (cross_es) {
         const size_t H = c.n_heads, HD = WH_HEAD_DIM;
         std::vector<float> wkT(H * d * HD);
@@ -827,11 +823,9 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
             lmc[n] = (float)cacc;
         }
     } else {
-        st.planar = x3;
         o_lmw = st.reserve((size_t)c.vocab * d * m->esz);
         fold_ln(o_lmw, 0, T(dd + ".embed_tokens.weight"), c.vocab, d, 1.0f, T(dd + ".layer_norm.weight"), T(dd + ".layer_norm.bias"), nullptr,
                 lms.data(), lmc.data());
-        st.planar = false;
     }
     size_t o_lms = st.put_f32(lms.data(), c.vocab), o_lmc = st.put_f32(lmc.data(), c.vocab);
     // log-mel tables
