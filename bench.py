@@ -111,6 +111,46 @@ def cpu_baseline(dims, seed: int, prompt, eot, max_new: int, levels=None) -> dic
             "seconds": best["seconds"], "clip_parallel_sweep": sweep, "tokens": out[0][3]}
 
 
+def cpu_budget(cap: int = 64) -> int:
+    """Host cores this process may use: min(affinity mask, cgroup CPU quota, cap) — the GPU boxes expose every hardware thread of the
+    host but grant a share of them."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt[0] != "max":
+            n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, min(n, cap))
+
+
+def init_group(rank: int, world: int, prefer_nccl: bool, local_rank: int):
+    """The process group of the result gather: RCCL (backend "nccl") when asked for and available, else gloo — the gather is a few KB.
+    A failed RCCL initialisation must leave nothing half-built behind before gloo is tried.  Returns (dist, backend, error text or None)."""
+    import torch.distributed as dist
+    err = None
+    if prefer_nccl:
+        try:
+            import torch
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL on ROCm
+            dist.barrier()
+            return dist, "nccl", None
+        except Exception as e:  # RCCL unavailable
+            err = f"{type(e).__name__}: {e}"
+            print(f"[bench] nccl init failed ({err}); falling back to gloo", file=sys.stderr)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist, "gloo", err
+
+
 def self_launch(n: int) -> int:
     """One process per GPU: start n copies of this script as children with RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* set, relay rank 0's stdout (the JSON line), return non-zero if any rank fails.
@@ -166,8 +206,9 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clips", type=int, default=0,
-                    help="clips per GPU per step (one device batch resident in HBM); default: the largest batch the preset's "
-                         "workspace allows — 1024 for whisper-base (≈50 GB of workspace + caches), 256 for whisper-large-v3 (≈99 GB)")
+                    help="clips per GPU per step (one device batch resident in HBM); default: the library's largest batch for the preset — "
+                         "2048 for whisper-base (≈72 GB of workspace + caches in bf16, ≈125 GB in the f16x3 mode), 256 for whisper-large-v3 (≈99 GB); "
+                         "a quarter of that in the exact-f32 mode")
     ap.add_argument("--total-clips", type=int, default=0,
                     help="strong scaling (BASELINE configs[2]/[4]: '512 clips sharded over N GPUs'): the whole job's clips per step, "
                          "dealt evenly to the ranks; overrides --clips and reports \"scaling\": \"strong\"")
@@ -187,7 +228,8 @@ def main() -> None:
     ap.add_argument("--max-new-tokens", type=int, default=128)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-batch1", action="store_true", help="skip the batch-1 latency side measurement (profiling runs)")
+    ap.add_argument("--no-batch1", action="store_true", help="skip the untimed side measurements: batch-1 latency, 64- / 256- / 1024-clip batches, host-resident clips, "
+                                                              "in-tolerance precisions, strong scaling (profiling runs)")
     ap.add_argument("--no-row-check", action="store_true",
                     help="skip the untimed one-clip / pipelined-vs-plain identity checks (profiling runs: their launches would dilute per-kernel averages)")
     ap.add_argument("--test-single-device", action="store_true",
@@ -200,6 +242,7 @@ def main() -> None:
                     help="no GPU work: every rank joins a gloo group, gathers one dummy record and rank 0 prints what it saw "
                          "(CPU test of the launcher and the rendezvous)")
     ap.add_argument("--fail-rank", type=int, default=-1, help="launcher test: with --launch-check, this rank exits with status 3 before the rendezvous")
+    ap.add_argument("--prefer-nccl", action="store_true", help="launcher test: with --launch-check, try the RCCL backend first (on a CPU box: exercises the fallback to gloo)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -224,16 +267,16 @@ def main() -> None:
         if a.fail_rank == rank:
             print(f"[bench] rank {rank}: --fail-rank asked this rank to die before the rendezvous", file=sys.stderr)
             raise SystemExit(3)
-        import torch.distributed as dist
         from whisper_rust_ort_amd import sharding
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist, lc_backend, lc_err = init_group(rank, world, a.prefer_nccl, local_rank)
         ids = sharding.shard_clip_ids(rank, world, 2)
         rec = sharding.gather_records(dist, sharding.pack_records(ids, [np.array([rank, local_rank])] * 2, 4))
         tmax = sharding.max_over_ranks(dist, float(rank))
         if rank == 0:
             print(json.dumps({"launch_check": True, "world": world, "max_rank": tmax, "scaling": scaling, "clips_per_gpu": a.clips,
+                              "backend": lc_backend, "nccl_error": lc_err, "host_threads_per_rank": max(1, cpu_budget() // world),
                               "records": [[c, t.tolist()] for c, t in sharding.unpack_records(rec)]}), flush=True)
         dist.barrier()
         dist.destroy_process_group()
@@ -241,26 +284,11 @@ def main() -> None:
     dist = None
     backend = "none"
     if world > 1 or a.force_dist:
-        import torch
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if a.test_single_device:
             local_rank = 0
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            backend = "gloo"
-        else:
-            torch.cuda.set_device(local_rank)
-            try:
-                dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL on ROCm
-                backend = "nccl"
-                dist.barrier()
-            except Exception as e:  # RCCL unavailable: the result gather is tiny, gloo carries it
-                print(f"[bench] nccl init failed ({e}); falling back to gloo", file=sys.stderr)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-                backend = "gloo"
+        dist, backend, _ = init_group(rank, world, not a.test_single_device, local_rank)
 
     dims = ms.PRESETS[a.preset]
     prec = wb.PRECISIONS[a.precision]
@@ -273,6 +301,8 @@ def main() -> None:
         a.clips = {"base": 2048, "large-v3": 256}.get(a.preset, 256)
         if prec == wb.WH_PREC_F32 and a.preset in ("base", "large-v3"):
             a.clips //= 4
+        if prec == wb.WH_PREC_F16X3 and a.preset == "large-v3":
+            a.clips //= 2   # f32-sized activations and K / V cache: ≈ 0.8 GB per clip
     if a.pipeline is None:
         a.pipeline = DEFAULT_PIPELINE if a.streams == 1 else 0
     if a.pipeline and a.streams != 1:
@@ -304,7 +334,8 @@ def main() -> None:
     n_bufs = 2 if a.pipeline else 1
     d_bufs = []
     for k in range(n_bufs):
-        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as gen:   # numpy releases the GIL in the bulk of it
+        # clip synthesis threads: this rank's share of the host cores the job may use (8 ranks x 16 threads would oversubscribe a cgroup share)
+        with ThreadPoolExecutor(max_workers=max(1, min(16, cpu_budget() // world))) as gen:   # numpy releases the GIL in the bulk of it
             pcm = np.stack(list(gen.map(lambda i: ms.synth_clip(1000000 * k + rank * a.clips + i), range(a.clips))))
         d_bufs.append(hip.upload(dev, pcm))
         del pcm
@@ -411,6 +442,7 @@ def main() -> None:
             live["launches"] += pg["launches"]
     barrier()
     elapsed = time.perf_counter() - t0
+    cross_es_mode = ctxs[0].cross_mode == 1
     if dist is not None:
         from whisper_rust_ort_amd import sharding
         dev_t = "cuda" if backend == "nccl" else "cpu"
@@ -475,15 +507,103 @@ def main() -> None:
         b1024 = {"ms_per_batch": float(np.median(t1024)), "rtfx": 1024 * 30e3 / float(np.median(t1024)),
                  "note": "one 1024-clip device batch per call (the per-step workload of the round-2 / round-3 lines)"}
 
+    # ---- the same clips from page-locked HOST memory (the reference's end_to_end_s counts the load, src/main.rs:1190): wh_transcribe_batch_next
+    # copies batch i + 1 to the device on a copy stream beside batch i's work, so a step pays what is left of its own copy
+    host_res = None
+    if rank == 0 and world == 1 and not a.no_batch1 and not a.pipeline and a.streams == 1:
+        try:
+            hbuf = hip.host_alloc((a.clips, 480000), np.float32)
+            with ThreadPoolExecutor(max_workers=max(1, min(16, cpu_budget()))) as gen:
+                list(gen.map(lambda i: hbuf.__setitem__(i, ms.synth_clip(rank * a.clips + i)), range(a.clips)))
+            rows = [hbuf[i] for i in range(a.clips)]
+            ctx.profile_enable(False)
+            got = ctx.transcribe_batch_next(rows, params, rows)          # untimed: copies this batch now, prefetches the next
+            assert [t.tolist() for t in got[:4]] == [t.tolist() for t in toks[:4]], "host-resident entry differs from the device-resident one"
+            hl = []
+            hip.sync()
+            th0 = time.perf_counter()
+            for _ in range(3):
+                t1 = time.perf_counter()
+                ctx.transcribe_batch_next(rows, params, rows)
+                hl.append(time.perf_counter() - t1)
+            hip.sync()
+            hel = time.perf_counter() - th0
+            tmh = ctx.timings()
+            host_res = {"rtfx": 30.0 * a.clips * 3 / hel, "ms_per_step": hel / 3 * 1e3, "p95_ms_per_clip": float(np.percentile(np.asarray(hl) * 1e3, 95)),
+                        "h2d_wait_ms_last_step": tmh["h2d_s"] * 1e3, "h2d_bytes_per_step": int(a.clips) * 480000 * 4,
+                        "note": "the same clips in page-locked host memory through wh_transcribe_batch_next: every step copies its successor's PCM "
+                                "(1.92 MB per clip) host-to-device on a copy stream beside its own log-mel / encoder / token loop; 3 steps"}
+            hip.host_free(hbuf)
+        except Exception as e:   # a side measurement must not cost the line
+            host_res = {"error": f"{type(e).__name__}: {e}"}
+    # ---- BASELINE configs[2]'s own reading of scaling: a FIXED job of 512 clips dealt to the ranks (strong scaling), beside the weak-scaling headline
+    strong = None
+    if scaling == "weak" and not a.no_batch1 and not a.pipeline and (512 % world) == 0 and 512 // world <= a.clips:
+        cs = 512 // world
+        ctx_s = wb.Context(model, cs)
+        ctx_s.transcribe_batch_device(d_pcm, cs, params)
+        barrier()
+        ts0 = time.perf_counter()
+        for _ in range(3):
+            ctx_s.transcribe_batch_device(d_pcm, cs, params)
+        barrier()
+        tse = time.perf_counter() - ts0
+        ctx_s.close()
+        if dist is not None:
+            from whisper_rust_ort_amd import sharding
+            tse = sharding.max_over_ranks(dist, tse, "cuda" if backend == "nccl" else "cpu")
+        strong = {"total_clips_per_step": 512, "clips_per_gpu": cs, "steps": 3, "ms_per_step": tse / 3 * 1e3, "value": 30.0 * 512 * 3 / tse,
+                  "note": "BASELINE configs[2]: 512 clips per step sharded over the GPUs of the job (fixed total work); the headline `value` is the weak-scaling reading"}
+    # ---- the precisions that meet north_star's tolerance (tokens identical to the f32 reference, logits within 1e-3): the headline dtype is
+    # BASELINE's bf16, which does not (tests/test_hip_parity.py bounds it at 0.16); these are measured in the same run, after the main context
+    # has given its memory back
+    in_tol = None
+    if rank == 0 and world == 1 and not a.no_batch1 and prec in (wb.WH_PREC_BF16, wb.WH_PREC_FP8) and a.preset == "base":
+        try:
+            for cx in ctxs:
+                cx.close()
+            ctxs = []
+            mx = wb.Model(f"synthetic:{a.preset}:{a.seed}", dev, wb.WH_PREC_F16X3)
+            cxx = wb.Context(mx, a.clips)
+            tx = cxx.transcribe_batch_device(d_pcm, a.clips, params)
+            hip.sync()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                tx = cxx.transcribe_batch_device(d_pcm, a.clips, params)
+            hip.sync()
+            ex = (time.perf_counter() - t1) / 2
+            tmx = cxx.timings()
+            cxx.close()
+            m32 = wb.Model(f"synthetic:{a.preset}:{a.seed}", dev, wb.WH_PREC_F32)
+            n32 = min(512, a.clips)
+            c32 = wb.Context(m32, n32)
+            t32 = c32.transcribe_batch_device(d_pcm, n32, params)
+            hip.sync()
+            t1 = time.perf_counter()
+            t32 = c32.transcribe_batch_device(d_pcm, n32, params)
+            hip.sync()
+            e32 = time.perf_counter() - t1
+            c32.close()
+            same = sum(int(tx[i].tolist() == t32[i].tolist()) for i in range(n32))
+            in_tol = {"dtype": "f16x3", "clips_per_step": a.clips, "steps": 2, "ms_per_step": ex * 1e3, "rtfx": 30.0 * a.clips / ex, "p95_ms_per_clip": ex * 1e3,
+                      "stage_ms": {k: tmx[k] * 1e3 for k in ("preprocess_s", "encode_s", "decode_s")},
+                      "tokens_identical_to_exact_f32": f"{same}/{n32} clips x {a.max_new_tokens} tokens",
+                      "exact_f32": {"dtype": "f32", "clips_per_step": n32, "steps": 1, "ms_per_step": e32 * 1e3, "rtfx": 30.0 * n32 / e32},
+                      "note": "WH_PREC_F16X3: every contraction on the fp16 matrix cores with both operands as two fp16 limbs (22 significant bits), three MFMAs "
+                              "per product, f32 everywhere else; held to the golden vectors at 1e-3 with tokens exact by tests/test_hip_parity.py "
+                              "(measured 5e-5) like the exact-f32 MFMA mode beside it"}
+        except Exception as e:
+            in_tol = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
-        cross_es = ctxs[0].cross_mode == 1
+        cross_es = cross_es_mode
         work = algorithmic_work(dims, per_stream, len(prompt), a.max_new_tokens, 1 if prec == wb.WH_PREC_FP8 else esz, cross_es)
         audio_s = 30.0 * a.clips * a.steps * world
         ms_per_step = elapsed / a.steps * 1e3
-        # Roofline of the dominant kernel (k_dec_cross_attn: largest single-kernel share in every
-        # rocprofv3 --stats summary under profiles/).  `achieved` = algorithmic bytes per launch
-        # (K and V of one decoder layer for every clip of the launch) ÷ the average launch
-        # duration measured with HIP events on the launch stream over the TIMED region.
+        # Roofline of the dominant kernel (the decoder cross-attention: largest single-kernel share in every rocprofv3 --stats
+        # summary under profiles/).  `achieved` = the algorithmic bytes of one launch — the encoder states of every clip of the launch
+        # once (k_dec_cross_attn_es*), or K and V of one decoder layer (k_dec_cross_attn*) — ÷ the average launch duration
+        # measured with HIP events on the launch stream over the TIMED region.
         tot_ms = sum(v["ms"] for v in breakdown.values())
         if a.graph_timed:
             live = {"ms": breakdown["dec_cross_attn"]["ms"] * a.streams, "launches": breakdown["dec_cross_attn"]["launches"]}
@@ -492,7 +612,7 @@ def main() -> None:
         traffic = None
         traffic_stamp = None
         # the dominant kernel's variants: e4m3 cache (fp8 mode), one workgroup per 256-column group (wide models), all heads per workgroup
-        dom_kernel = ("k_dec_cross_attn_es" if cross_es else "k_dec_cross_attn8" if prec == wb.WH_PREC_FP8 else
+        dom_kernel = ("k_dec_cross_attn_es2" if (cross_es and prec == wb.WH_PREC_F16X3) else "k_dec_cross_attn_es" if cross_es else "k_dec_cross_attn8" if prec == wb.WH_PREC_FP8 else
                       "k_dec_cross_attn_cg" if (prec == wb.WH_PREC_BF16 and dims.d_model > 512 and dims.d_model % 256 == 0) else "k_dec_cross_attn")
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):   # HBM bytes per launch from rocprofv3 --pmc passes (see profiles/README.md)
@@ -569,6 +689,10 @@ def main() -> None:
             "batch64": b64,
             "batch256": b256,
             "batch1024": b1024,
+            "host_resident": host_res,
+            "in_tolerance": in_tol,
+            "scaling_weak": {"clips_per_gpu": a.clips, "total_clips_per_step": a.clips * world, "ms_per_step": ms_per_step, "value": audio_s / elapsed} if scaling == "weak" else None,
+            "scaling_strong": strong if scaling == "weak" else {"total_clips_per_step": a.clips * world, "clips_per_gpu": a.clips, "ms_per_step": ms_per_step, "value": audio_s / elapsed},
             "stage_ms_per_step": {k: v / a.steps * 1e3 for k, v in stage.items()},
             "kernel_group_ms_per_step": {k: round(v["ms"], 3) for k, v in breakdown.items()},
             "kernel_group_launches": {k: v["launches"] for k, v in breakdown.items()},

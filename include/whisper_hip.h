@@ -185,6 +185,12 @@ int wh_decode_greedy(wh_ctx* c, const wh_decode_params* p, int64_t* tokens_out, 
 int wh_decode_greedy_batch(wh_ctx* c, const wh_decode_params* p, int64_t* tokens_out, size_t cap_tokens, size_t* n_tokens_out,
                            size_t cap_clips, size_t* n_clips_out, float* logits_out, size_t cap_logits_rows);
 
+/* The same, reading back the logits of n_rows chosen batch rows only (rows[i] in 0 .. n-1, each once): logits_out is
+ * [n_rows][cap_logits_rows][vocab].  Tokens come back for every clip.  Lets the parity tests hold a 2048-clip context to the golden
+ * vectors over a whole forced history (all rows' logits would be 10 GB). */
+int wh_decode_greedy_rows(wh_ctx* c, const wh_decode_params* p, const int32_t* rows, size_t n_rows, int64_t* tokens_out, size_t cap_tokens,
+                          size_t* n_tokens_out, size_t cap_clips, size_t* n_clips_out, float* logits_out, size_t cap_logits_rows);
+
 /* ---- fused batch call: the body of transcribe_longform_chunked for ≤ max_batch single-window
  * clips (src/main.rs:870-915 / 946-967) run as one batch on the ctx stream -------------------- */
 typedef struct {
@@ -194,6 +200,15 @@ typedef struct {
 /* tokens_out: [n_clips][n_prompt + max_new_tokens] row-major; n_tokens_out: [n_clips]. */
 int wh_transcribe_batch(wh_ctx* c, const wh_clip* clips, size_t n_clips, const wh_decode_params* p,
                         int64_t* tokens_out, size_t* n_tokens_out);
+/* wh_transcribe_batch with the NEXT batch's host-to-device copy taken off the critical path (the reference's file loop loads file
+ * i + 1 only after file i is done, src/main.rs:1164-1213; its `end_to_end_s` counts the load, :1190).  Transcribes `clips` like
+ * wh_transcribe_batch and, if next_clips != NULL, copies their PCM into the context's second device buffer on a copy stream, beside this
+ * batch's log-mel, encoder and token loop (asynchronous for page-locked host memory; pageable memory still works, staged by the
+ * runtime).  A following call whose clips start at the same host address, with the same count and lengths, finds its PCM resident (or
+ * on its way) and only waits for the copy's event; any other call copies as wh_transcribe_batch does.  next_clips' memory must stay
+ * valid and unchanged until that call.  Results are identical to wh_transcribe_batch. */
+int wh_transcribe_batch_next(wh_ctx* c, const wh_clip* clips, size_t n_clips, const wh_clip* next_clips, size_t n_next,
+                             const wh_decode_params* p, int64_t* tokens_out, size_t* n_tokens_out);
 /* Same with PCM already resident in device memory: d_pcm is [n_clips][480000] f32 on the ctx's
  * device (each clip exactly 30 s).  This is the entry bench.py times (inputs resident in HBM). */
 int wh_transcribe_batch_device(wh_ctx* c, const float* d_pcm, size_t n_clips, const wh_decode_params* p,

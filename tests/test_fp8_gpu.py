@@ -59,7 +59,8 @@ def test_fp8_teacher_forced_vs_quantised_oracle(gpu, preset, seed, clip, n_new):
     tc, lc = ctx.greedy_decode_with_past(wb.DecodeParams(prompt, n_new, eot, [eot], forced=gen[:-1]), want_logits=True)
     assert len(lc) == len(log_o)
     errs = [np.abs(lc[i] - log_o[i]).max() for i in range(len(lc))]
-    bound = 2.0 * max(errs)
+    err_bound = 1.5 if mx else 0.25   # MX: the bound of test_fp8_base_256_vs_64_clip_context_logit_bound (quantisation noise of this synthetic model)
+    bound = 2.0 * err_bound           # a fixed margin: twice the bound asserted below, not twice the measured error
     decided = agree = 0
     for i in range(len(lc)):
         top2 = np.partition(log_o[i], -2)[-2:]
@@ -68,7 +69,7 @@ def test_fp8_teacher_forced_vs_quantised_oracle(gpu, preset, seed, clip, n_new):
             agree += int(tc[len(prompt) + i] == gen[i])
     print(f"{preset}: fp8 vs quantised oracle: encoder err {enc_err:.4f}, max logit err {max(errs):.4f}, "
           f"mean {np.mean(errs):.4f}; decided {decided}/{len(lc)} agree {agree}")
-    assert max(errs) < (1.5 if mx else 0.25)   # MX: the bound of test_fp8_base_256_vs_64_clip_context_logit_bound (quantisation noise of this synthetic model)
+    assert max(errs) < err_bound
     assert agree == decided
 
     # the quantisation itself moves the logits by far more than the bf16 arithmetic does: the fp8 run must sit

@@ -286,10 +286,17 @@ def test_argmax_edge_cases_via_suppress_all_but_one(gpu):
 # ------------------------------------------------------------------------------------------------
 # bf16 mode
 # ------------------------------------------------------------------------------------------------
+# bf16 against the f32 golden vectors: ABSOLUTE bounds (round-3 verdict: a bound of 2 x the measured error moves with what it bounds).
+# Measured on MI355X with the encoder LayerNorm fold: encoder states 0.070 (micro) / 0.081 (base), logits 0.080 (micro) / 0.132 (base) on
+# logits of sigma 1.3; a token is "decided" where the f32 top-1 margin exceeds twice the logit bound — there the argmax must agree.
+BF16_ENC_BOUND, BF16_LOGIT_BOUND = 0.10, 0.16
+BF16_MIN_DECIDED = {"micro": 1, "base": 1}   # steps of the 24-step golden history whose f32 top-1 margin exceeds 2 x the logit bound
+
+
 @pytest.mark.parametrize("preset,seed,clip", [("micro", 11, 2), ("base", 1234, 0)])
 def test_bf16_teacher_forced_agreement(gpu, golden_dir, preset, seed, clip):
-    """bf16 MFMA path vs the fp32 golden vectors under teacher forcing: logit error is bounded and the
-    argmax agrees wherever the fp32 top-1 margin exceeds twice the measured error."""
+    """bf16 MFMA path vs the fp32 golden vectors under teacher forcing: encoder and logit errors inside fixed bounds, the argmax
+    agrees on every step whose fp32 top-1 margin exceeds twice the logit bound, and the golden history has such steps."""
     g = np.load(os.path.join(golden_dir, f"{preset}_s{seed}_c{clip}.npz"))
     b = bundle(preset, seed, wb.WH_PREC_BF16)
     pcm = ms.synth_clip(clip)
@@ -297,24 +304,35 @@ def test_bf16_teacher_forced_agreement(gpu, golden_dir, preset, seed, clip):
     np.testing.assert_allclose(mel[:, ::25], g["mel_slice"], rtol=0, atol=MEL_TOL)  # mel is f64/f32 in both modes
     enc = b.ctx.run_encoder(mel)
     enc_err = np.abs(enc[g["enc_rows"]] - g["enc_slice"]).max()
-    assert enc_err < 0.12, enc_err       # bf16 has 8 significand bits; states are O(1) with peaked attention: 0.07 (micro) / 0.081 (base) measured
+    assert enc_err < BF16_ENC_BOUND, enc_err
     prompt, eot = g["prompt"].tolist(), int(g["eot"])
     forced = g["forced_c"].tolist()
     tc, lc = b.ctx.greedy_decode_with_past(wb.DecodeParams(prompt, len(forced) + 1, eot, forced=forced), want_logits=True)
-    errs, agree, decided = [], 0, 0
-    for i in range(len(lc)):
-        ids, vals = g["top_ids_c"][i], g["top_vals_c"][i]
-        e = np.abs(lc[i][ids] - vals).max()
-        errs.append(e)
-    bound = 2.0 * max(errs)
-    for i in range(len(lc)):
-        vals = g["top_vals_c"][i]
-        if vals[0] - vals[1] > bound:
-            decided += 1
-            agree += int(tc[len(prompt) + i] == g["tokens_c"][len(prompt) + i])
-    print(f"{preset}: bf16 max logit err {max(errs):.4f}, mean {np.mean(errs):.4f}; decided {decided}/{len(lc)} agree {agree}")
-    assert max(errs) < 0.25
-    assert agree == decided
+    errs = [float(np.abs(lc[i][g["top_ids_c"][i]] - g["top_vals_c"][i]).max()) for i in range(len(lc))]
+    decided = [i for i in range(len(lc)) if g["top_vals_c"][i][0] - g["top_vals_c"][i][1] > 2.0 * BF16_LOGIT_BOUND]
+    agree = sum(int(tc[len(prompt) + i] == g["tokens_c"][len(prompt) + i]) for i in decided)
+    print(f"{preset}: bf16 enc err {enc_err:.4f}; max logit err {max(errs):.4f}, mean {np.mean(errs):.4f}; decided {len(decided)}/{len(lc)} agree {agree}")
+    assert max(errs) < BF16_LOGIT_BOUND
+    assert agree == len(decided)
+    assert len(decided) >= BF16_MIN_DECIDED[preset], (len(decided), "the golden history must keep steps with a clear f32 winner")
+
+
+def test_gemm8_off_switch_keeps_the_result_or_fails_loudly(gpu, golden_dir, monkeypatch):
+    """WH_GEMM8=0 (the documented A/B switch) on a bf16 context above the small-context size: every encoder GEMM goes to k_gemm, which has no
+    LayerNorm fold, so the context must not take the fold path (round-3 advisor: the launches were skipped and WH_OK returned).  The result is
+    held to the same golden bound as the default path; a GEMM that cannot run now fails the call instead of being skipped."""
+    g = np.load(os.path.join(golden_dir, "base_s1234_c0.npz"))
+    monkeypatch.setenv("WH_GEMM8", "0")
+    model = wb.Model("synthetic:base:1234", 0, wb.WH_PREC_BF16)
+    ctx = wb.Context(model, 32)
+    prompt, eot = g["prompt"].tolist(), int(g["eot"])
+    forced = g["forced_c"].tolist()
+    ctx.transcribe_batch([ms.synth_clip(0)] + [ms.synth_clip(310 + i) for i in range(31)], wb.DecodeParams(prompt, 2, eot, [eot]))
+    _, lg = ctx.greedy_decode_resident_rows(wb.DecodeParams(prompt, len(forced) + 1, eot, forced=forced), [0])
+    err = max(float(np.abs(lg[0][i][g["top_ids_c"][i]] - g["top_vals_c"][i]).max()) for i in range(len(forced) + 1))
+    print(f"WH_GEMM8=0, bf16 base, 32-clip context: max |logit - golden| {err:.4f}")
+    assert np.isfinite(lg[0]).all() and err < BF16_LOGIT_BOUND
+    ctx.close()
 
 
 def test_bf16_batch_is_deterministic_and_permutation_invariant(gpu):
@@ -395,19 +413,27 @@ def _ctx_logit_compare(prec, golden_dir, label, big=256):
     g0 = np.load(os.path.join(golden_dir, "base_s1234_c0.npz"))
     g3 = np.load(os.path.join(golden_dir, "base_s1234_c3.npz"))
     prompt, eot = g0["prompt"].tolist(), int(g0["eot"])
-    forced = g0["forced_c"].tolist()
-    if big > 256:
-        forced = forced[:7 if big <= 1024 else 3]                # logits read-back: big x rows x vocab floats
+    forced = g0["forced_c"].tolist()                             # the whole 23-step forced history at every context size
     distinct = [ms.synth_clip(0), ms.synth_clip(3)] + [ms.synth_clip(300 + i) for i in range(30)]
     b256 = bundle("base", 1234, prec, max_batch=big)
     b64 = bundle("base", 1234, prec, max_batch=64)
     fp = wb.DecodeParams(prompt, len(forced) + 1, eot, forced=forced)
     b256.ctx.transcribe_batch([distinct[i % 32] for i in range(big)], wb.DecodeParams(prompt, 2, eot, [eot]))
-    t256, l256 = b256.ctx.greedy_decode_resident_batch(fp, want_logits=True)
-    l256 = np.stack(l256)                                        # [big][rows][V]
-    for i in range(32, big):                                     # duplicates inside one context: identical arithmetic
-        assert np.array_equal(l256[i], l256[i % 32]), i
-        assert t256[i].tolist() == t256[i % 32].tolist()
+    if big > 256:
+        # wh_decode_greedy_rows: logits of the 32 distinct clips and of a few of their duplicates only (all rows would be 10 GB at 2048)
+        dup = [32, 33, big // 2 + 7, big - 32, big - 1]
+        t256, lsel = b256.ctx.greedy_decode_resident_rows(fp, list(range(32)) + dup)
+        l256 = np.stack(lsel[:32])
+        for j, r in enumerate(dup):
+            assert np.array_equal(lsel[32 + j], l256[r % 32]), r
+        for i in range(32, big):                                 # duplicates inside one context: identical tokens everywhere
+            assert t256[i].tolist() == t256[i % 32].tolist(), i
+    else:
+        t256, l256 = b256.ctx.greedy_decode_resident_batch(fp, want_logits=True)
+        l256 = np.stack(l256)                                    # [big][rows][V]
+        for i in range(32, big):                                 # duplicates inside one context: identical arithmetic
+            assert np.array_equal(l256[i], l256[i % 32]), i
+            assert t256[i].tolist() == t256[i % 32].tolist()
     b64.ctx.transcribe_batch(distinct, wb.DecodeParams(prompt, 2, eot, [eot]))
     t64, l64 = b64.ctx.greedy_decode_resident_batch(fp, want_logits=True)
     l64 = np.stack(l64)                                          # [32][24][V]
@@ -436,8 +462,8 @@ def _ctx_logit_compare(prec, golden_dir, label, big=256):
 def test_base_bf16_256_vs_64_clip_context_logit_bound(gpu, golden_dir, big):
     """Replaces the former 'at most 4 of 32 clips may diverge' allowance by a measured, per-row logit bound."""
     d_ctx, e256, e64, e3 = _ctx_logit_compare(wb.WH_PREC_BF16, golden_dir, "bf16", big)
-    assert d_ctx.max() < 0.12          # two bf16 summation orders of the same arithmetic on logits of std ~2.6
-    assert max(e256, e64, e3) < 0.25   # the bf16-vs-f32 bound of test_bf16_teacher_forced_agreement
+    assert d_ctx.max() < 0.12          # two bf16 summation orders / two forms of the cross-attention on logits of sigma 1.3 (measured 0.06-0.08)
+    assert max(e256, e64, e3) < BF16_LOGIT_BOUND   # the bf16-vs-f32 bound of test_bf16_teacher_forced_agreement, over the whole forced history
 
 
 # ------------------------------------------------------------------------------------------------
@@ -466,30 +492,26 @@ def test_f32_base_batched_contexts_match_golden(gpu, golden_dir, nb, prec_name):
     for r, c in rows.items():
         if c == 0:
             assert gb[r].tolist() == g[0]["tokens_b"].tolist(), r
-    # (c) logits of the batched decode: first 32 free-running rows, then each golden clip's teacher-forced history
-    n_free = 32 if nb <= 256 else (8 if nb <= 1024 else 4)   # logits read-back: nb x rows x vocab floats (1.7 GB at 256 x 32, 1024 x 8 and 2048 x 4)
-    ta, la = b.ctx.greedy_decode_resident_batch(wb.DecodeParams(prompt, n_free, eot), want_logits=True)
+    # (c) logits of the batched decode, read back for the golden rows only (wh_decode_greedy_rows: every context size sees the same
+    # 32 free-running steps and the whole teacher-forced history): first 32 free-running rows, then each golden clip's forced history
+    sel = sorted(rows)
+    ta, la = b.ctx.greedy_decode_resident_rows(wb.DecodeParams(prompt, 32, eot), sel)
     worst = 0.0
-    for r, c in rows.items():
-        n = len(la[r])
-        assert ta[r].tolist() == g[c]["tokens_a"][: len(prompt) + n].tolist()
+    for j, r in enumerate(sel):
+        c, n = rows[r], len(la[j])
+        assert n == 32 and ta[r].tolist() == g[c]["tokens_a"][: len(prompt) + n].tolist()
         for i in range(n):
-            worst = max(worst, float(np.abs(la[r][i][g[c]["top_ids_a"][i]] - g[c]["top_vals_a"][i]).max()))
+            worst = max(worst, float(np.abs(la[j][i][g[c]["top_ids_a"][i]] - g[c]["top_vals_a"][i]).max()))
     for c in (0, 3):
         forced = g[c]["forced_c"].tolist()
-        if nb > 256:
-            forced = forced[:7 if nb <= 1024 else 3]   # a prefix of the forced history: the rows see the same prefixes as the golden run
-        tc, lc = b.ctx.greedy_decode_resident_batch(wb.DecodeParams(prompt, len(forced) + 1, eot, forced=forced), want_logits=True)
-        for r, cc in rows.items():
-            if cc != c:
+        tc, lc = b.ctx.greedy_decode_resident_rows(wb.DecodeParams(prompt, len(forced) + 1, eot, forced=forced), sel)
+        for j, r in enumerate(sel):
+            if rows[r] != c:
                 continue
-            if nb > 256:
-                assert tc[r].tolist()[:-1] == g[c]["tokens_c"].tolist()[: len(prompt) + len(forced)], (r, c)
-            else:
-                assert tc[r].tolist() == g[c]["tokens_c"].tolist(), (r, c)
-            for i in range(len(lc[r])):
-                worst = max(worst, float(np.abs(lc[r][i][g[c]["top_ids_c"][i]] - g[c]["top_vals_c"][i]).max()))
-            np.testing.assert_allclose(lc[r][:4, :2048], g[c]["logits_c_head"], rtol=0, atol=LOGIT_TOL)
+            assert tc[r].tolist() == g[c]["tokens_c"].tolist(), (r, c)
+            for i in range(len(lc[j])):
+                worst = max(worst, float(np.abs(lc[j][i][g[c]["top_ids_c"][i]] - g[c]["top_vals_c"][i]).max()))
+            np.testing.assert_allclose(lc[j][:4, :2048], g[c]["logits_c_head"], rtol=0, atol=LOGIT_TOL)
     print(f"{prec_name} base, {nb}-clip context: max |logit - golden| over all compared rows {worst:.2e}")
     assert worst <= LOGIT_TOL
 
@@ -674,7 +696,7 @@ def test_cross_es_matches_projected_kv_and_golden(gpu, golden_dir, nb):
     e_kv = max(np.abs(out["kv"][0][i][g0["top_ids_c"][i]] - g0["top_vals_c"][i]).max() for i in range(len(forced) + 1))
     print(f"{nb} clips: encoder-state vs K/V form max |dlogit| {d.max():.4f} (median {np.median(d):.4f}); vs f32 golden: es {e_es:.4f}, kv {e_kv:.4f}")
     assert d.max() < 0.12                 # measured 0.07-0.08: two bf16 roundings of the same attention (logit std 1.3)
-    assert max(e_es, e_kv) < 0.25         # the bf16-vs-f32 bound of test_bf16_teacher_forced_agreement
+    assert max(e_es, e_kv) < BF16_LOGIT_BOUND   # the bf16-vs-f32 bound of test_bf16_teacher_forced_agreement
     srt = np.sort(out["kv"], axis=2)
     decided = (srt[:, :, -1] - srt[:, :, -2]) > 2.0 * d[:, None]
     assert (out["es"].argmax(axis=2)[decided] == out["kv"].argmax(axis=2)[decided]).all()

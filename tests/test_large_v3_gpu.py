@@ -76,8 +76,8 @@ def test_large_v3_f32_against_oracle():
 
 def _teacher_forced_vs_golden(ctx, g, rows, label, err_bound):
     """Teacher-forced decode of the resident batch on the golden token history `forced_c`: logit error of every golden row
-    against the f32 golden top-k values, and argmax agreement on the steps whose f32 top-1 margin exceeds twice the
-    measured error (the pattern of test_bf16_teacher_forced_agreement in test_hip_parity.py)."""
+    against the f32 golden top-k values inside the fixed bound, and argmax agreement on the steps whose f32 top-1 margin exceeds
+    twice that bound (the pattern of test_bf16_teacher_forced_agreement in test_hip_parity.py)."""
     prompt, eot = g["prompt"].tolist(), int(g["eot"])
     forced = g["forced_c"].tolist()
     tc, lc = ctx.greedy_decode_resident_batch(wb.DecodeParams(prompt, len(forced) + 1, eot, forced=forced), want_logits=True)
@@ -92,7 +92,7 @@ def _teacher_forced_vs_golden(ctx, g, rows, label, err_bound):
     for r in rows:
         for i in range(len(lc[r])):
             vals = g["top_vals_c"][i]
-            if vals[0] - vals[1] > 2.0 * worst:
+            if vals[0] - vals[1] > 2.0 * err_bound:   # a fixed margin (twice the bound asserted below), not one that moves with the measured error
                 decided += 1
                 agree += int(tc[r][len(prompt) + i] == g["tokens_c"][len(prompt) + i])
     # all golden rows hold the same clip in the same context: identical to the last bit
@@ -129,7 +129,7 @@ def test_large_v3_bf16_teacher_forced_vs_golden(golden_dir, nb):
         assert enc_err < 0.2, enc_err
     else:
         ctx.transcribe_batch(clips, wb.DecodeParams(prompt, 1, eot))   # leaves the batch's encoder states resident
-    _teacher_forced_vs_golden(ctx, g, rows, f"large-v3 bf16, {nb}-clip context", 0.5)
+    _teacher_forced_vs_golden(ctx, g, rows, f"large-v3 bf16, {nb}-clip context", 0.16)   # measured 0.08-0.11 on logits of magnitude 7.6
 
 
 def test_large_v3_fp8_teacher_forced_vs_golden(golden_dir):
@@ -145,7 +145,7 @@ def test_large_v3_fp8_teacher_forced_vs_golden(golden_dir):
         rows = sorted({0, nb - 1})
         clips = [gold if i in rows else ms.synth_clip(40 + (i % 5)) for i in range(nb)]
         ctx.transcribe_batch(clips, wb.DecodeParams(prompt, 1, eot))
-        _teacher_forced_vs_golden(ctx, g, rows, f"large-v3 fp8, {nb}-clip context", 4.0)
+        _teacher_forced_vs_golden(ctx, g, rows, f"large-v3 fp8, {nb}-clip context", 1.2)   # measured 0.79 (e4m3 weights, MX activations, e4m3 K / V)
         ctx.close()
 
 

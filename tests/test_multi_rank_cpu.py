@@ -136,3 +136,37 @@ def test_bench_launcher_fails_when_one_rank_dies():
     assert "rank 2 exited with 3" in out.stderr
     assert not any(l.startswith("{") for l in out.stdout.splitlines())      # no result line from a failed job
     assert time.time() - t0 < 120
+
+
+def test_nccl_init_failure_falls_back_to_gloo_cleanly():
+    """bench.py's process-group initialisation (init_group): asked for RCCL on a box without a GPU, the "nccl" backend fails; the
+    fallback must leave no half-initialised group behind and gather over gloo — both ranks finish, rank 0 reports the backend and
+    the error it fell back from.  Also: the per-rank host-thread cap divides the cgroup's cores by the world size."""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check", "--prefer-nccl"], env=_clean_env(),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["world"] == 2 and line["backend"] == "gloo" and line["nccl_error"]
+    assert "falling back to gloo" in out.stderr
+    assert [c for c, _ in line["records"]] == [0, 1, 2, 3]
+    assert 1 <= line["host_threads_per_rank"] <= max(1, (os.cpu_count() or 1) // 2)
+
+
+def test_cli_devices_flag_maps_to_one_model_per_device_and_contexts_per_stream():
+    """whisper_bench --devices 0-7 --streams-per-gpu 2 --print-plan: the plan the CLI derives from the flags (one model per device, one
+    context and host thread per (device, stream)) without touching a device; list and range forms, a bad range is an error."""
+    import json
+    import subprocess
+    cli = os.path.join(ROOT, "whisper-rust-ort_amd", "whisper_bench")
+    r = subprocess.run([cli, "--onnx-dir", "synthetic:base:1", "--devices", "0-7", "--streams-per-gpu", "2", "--max-batch", "64", "--print-plan"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    plan = json.loads(r.stdout)
+    assert plan["devices"] == list(range(8)) and plan["models"] == 8 and plan["host_threads"] == 16 and plan["max_batch"] == 64
+    assert [(c["context"], c["device"], c["stream"]) for c in plan["contexts"]] == [(2 * d + s, d, s) for d in range(8) for s in range(2)]
+    r = subprocess.run([cli, "--onnx-dir", "synthetic:base:1", "--devices", "1,3-4", "--print-plan"], capture_output=True, text=True, timeout=60)
+    assert json.loads(r.stdout)["devices"] == [1, 3, 4]
+    r = subprocess.run([cli, "--onnx-dir", "synthetic:base:1", "--devices", "5-2", "--print-plan"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "bad --devices range" in r.stderr

@@ -31,8 +31,8 @@ STATUS = {0: "WH_OK", 1: "WH_ERR_EMPTY_AUDIO", 2: "WH_ERR_BAD_SHAPE", 3: "WH_ERR
 # every symbol include/whisper_hip.h declares
 EXPORTS = ("wh_model_load", "wh_model_create", "wh_model_free", "wh_model_get_dims", "wh_model_precision",
            "wh_model_export_tensor", "wh_ctx_create", "wh_ctx_create_ex", "wh_ctx_free", "wh_ctx_cross_mode", "wh_last_error", "wh_get_timings",
-           "wh_mel_frames", "wh_log_mel", "wh_encode", "wh_decode_greedy", "wh_decode_greedy_batch", "wh_transcribe_batch",
-           "wh_transcribe_batch_device", "wh_transcribe_batch_device_next", "wh_longform_plan", "wh_transcribe_longform", "wh_profile_enable",
+           "wh_mel_frames", "wh_log_mel", "wh_encode", "wh_decode_greedy", "wh_decode_greedy_batch", "wh_decode_greedy_rows", "wh_transcribe_batch",
+           "wh_transcribe_batch_next", "wh_transcribe_batch_device", "wh_transcribe_batch_device_next", "wh_longform_plan", "wh_transcribe_longform", "wh_profile_enable",
            "wh_profile_get", "wh_synthetic_weights", "wh_e4m3_quantize", "wh_e4m3_dequantize", "wh_abi_version",
            "wh_device_count")
 
@@ -120,7 +120,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.wh_encode.argtypes = [vp, f32p, f32p]
     L.wh_decode_greedy.argtypes = [vp, C.POINTER(WhDecodeParams), i64p, C.c_size_t, szp, f32p, C.c_size_t]
     L.wh_decode_greedy_batch.argtypes = [vp, C.POINTER(WhDecodeParams), i64p, C.c_size_t, szp, C.c_size_t, szp, f32p, C.c_size_t]
+    L.wh_decode_greedy_rows.argtypes = [vp, C.POINTER(WhDecodeParams), C.POINTER(C.c_int32), C.c_size_t, i64p, C.c_size_t, szp, C.c_size_t, szp, f32p, C.c_size_t]
     L.wh_transcribe_batch.argtypes = [vp, C.POINTER(WhClip), C.c_size_t, C.POINTER(WhDecodeParams), i64p, szp]
+    L.wh_transcribe_batch_next.argtypes = [vp, C.POINTER(WhClip), C.c_size_t, C.POINTER(WhClip), C.c_size_t, C.POINTER(WhDecodeParams), i64p, szp]
     L.wh_transcribe_batch_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(WhDecodeParams), i64p, szp]
     L.wh_transcribe_batch_device_next.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(WhDecodeParams), i64p, szp]
     L.wh_longform_plan.argtypes = [C.c_size_t, C.c_double, C.c_double, szp, C.c_size_t, szp]
@@ -306,7 +308,40 @@ class Context:
         lg = [logits[i, : n[i] - len(params.prompt)] for i in range(k)] if want_logits else None
         return out, lg
 
+    def greedy_decode_resident_rows(self, params: DecodeParams, rows: Sequence[int]) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+        """The same batch decode with the logits of the chosen batch rows only (wh_decode_greedy_rows): tokens of every clip,
+        logits [len(rows)][generated][vocab]."""
+        p, keep = params.to_c()
+        cap = len(params.prompt) + params.max_new_tokens
+        nb = self.max_batch
+        toks = np.zeros((nb, cap), np.int64)
+        n = (C.c_size_t * nb)()
+        got = C.c_size_t(0)
+        sel = np.ascontiguousarray(rows, np.int32)
+        logits = np.zeros((len(sel), params.max_new_tokens, self.model.dims.vocab), np.float32)
+        self._check(self.lib.wh_decode_greedy_rows(self.h, C.byref(p), sel.ctypes.data_as(C.POINTER(C.c_int32)), len(sel), _i64(toks), cap, n, nb,
+                                                   C.byref(got), _f32(logits), params.max_new_tokens))
+        k = int(got.value)
+        out = [toks[i, : n[i]].copy() for i in range(k)]
+        return out, [logits[j, : n[int(r)] - len(params.prompt)] for j, r in enumerate(sel)]
+
     # --- fused batch entries ----------------------------------------------------------------------
+    def transcribe_batch_next(self, clips: Sequence[np.ndarray], params: DecodeParams, next_clips: Optional[Sequence[np.ndarray]] = None
+                              ) -> List[np.ndarray]:
+        """wh_transcribe_batch_next: `clips` transcribed like transcribe_batch while `next_clips` (arrays that stay alive and unchanged
+        until the call that transcribes them — views of page-locked memory make the copy asynchronous) are copied to the device."""
+        arrs = [np.ascontiguousarray(c, np.float32) for c in clips]
+        cl = (WhClip * len(arrs))(*[WhClip(_f32(a), a.size) for a in arrs])
+        nxt = [np.ascontiguousarray(c, np.float32) for c in next_clips] if next_clips is not None else None
+        ncl = (WhClip * len(nxt))(*[WhClip(_f32(a), a.size) for a in nxt]) if nxt else None
+        p, keep = params.to_c()
+        stride = len(params.prompt) + params.max_new_tokens
+        toks = np.zeros((len(arrs), stride), np.int64)
+        n = (C.c_size_t * len(arrs))()
+        self._check(self.lib.wh_transcribe_batch_next(self.h, cl, len(arrs), ncl, len(nxt) if nxt else 0, C.byref(p), _i64(toks), n))
+        self._keep_next = nxt   # (contiguous copies, if any were made, must outlive the asynchronous copy)
+        return [toks[i, : n[i]].copy() for i in range(len(arrs))]
+
     def transcribe_batch(self, clips: Sequence[np.ndarray], params: DecodeParams) -> List[np.ndarray]:
         arrs = [np.ascontiguousarray(c, np.float32) for c in clips]
         cl = (WhClip * len(arrs))(*[WhClip(_f32(a), a.size) for a in arrs])
@@ -451,6 +486,22 @@ class HipRuntime:
 
     def free(self, ptr: int):
         self.check(self.lib.hipFree(C.c_void_p(ptr)), "hipFree")
+
+    def host_alloc(self, shape, dtype=np.float32) -> np.ndarray:
+        """Page-locked host memory as a numpy array (hipHostMalloc): the source of truly asynchronous host-to-device copies."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self.lib.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+        self.check(self.lib.hipHostMalloc(C.byref(p), n, 0), "hipHostMalloc")
+        buf = (C.c_char * n).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr: np.ndarray):
+        self.lib.hipHostFree.argtypes = [C.c_void_p]
+        self.check(self.lib.hipHostFree(C.c_void_p(self._pinned.pop(arr.ctypes.data))), "hipHostFree")
 
     def sync(self):
         self.check(self.lib.hipDeviceSynchronize(), "hipDeviceSynchronize")

@@ -276,8 +276,10 @@ void pack_mask(const int64_t* a, size_t na, const int64_t* b, size_t nb, int voc
 // `after_kv` (optional) runs on the host right after the cross-K/V projection has been enqueued and its completion event
 // recorded: the place where the NEXT batch's encoder pass is put on the encoder stream, before the host is tied up in the
 // token loop.
+// `sel` (optional, with logits_out): the n_sel batch rows whose logits are read back — logits_out is then [n_sel][logits_rows][vocab]
 int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out, size_t tok_stride,
-               size_t* n_tokens_out, float* logits_out, size_t logits_rows, const std::function<int()>& after_kv = nullptr) {
+               size_t* n_tokens_out, float* logits_out, size_t logits_rows, const std::function<int()>& after_kv = nullptr,
+               const int32_t* sel = nullptr, size_t n_sel = 0) {
     wh_model* m = c->m;
     const wh_dims& D = m->dims;
     hipStream_t s = c->stream;
@@ -320,8 +322,19 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     CTX_HIP(c, hipStreamSynchronize(s));  // host vectors above go out of scope
 
     float* d_logits = nullptr;
+    const int* d_sel = nullptr;
+    const size_t n_lrows = sel ? n_sel : (size_t)nb;   // batch rows whose logits are kept
+    if (logits_out && sel) {
+        std::vector<int> map(nb, -1);
+        for (size_t i = 0; i < n_sel; i++) {
+            if (sel[i] < 0 || sel[i] >= nb || map[sel[i]] >= 0) return fail(c, WH_ERR_ARG, "decode: logits row %d outside the batch or listed twice", (int)sel[i]);
+            map[sel[i]] = (int)i;
+        }
+        CTX_HIP(c, hipMemcpy(c->logits_sel, map.data(), nb * 4, hipMemcpyHostToDevice));
+        d_sel = c->logits_sel;
+    }
     if (logits_out) {
-        const size_t need = (size_t)nb * logits_rows * D.vocab;
+        const size_t need = n_lrows * logits_rows * D.vocab;
         if (need > c->logits_cap) {
             drop_step_graph(c);  // the captured step holds the old buffer's address
             if (c->logits) CTX_HIP(c, hipFree(c->logits));
@@ -499,7 +512,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 a.M = nb; a.N = D.vocab; a.K = (int)d;
                 a.X = c->dxs; a.x_mpad = mpad;
                 a.pos_p = c->pos; a.n_prompt = P; a.mask_first = c->mask_first; a.mask_base = c->mask_base;
-                a.logits = d_logits; a.logits_rows = (int)logits_rows; a.part_val = c->part_val; a.part_idx = c->part_idx;
+                a.logits = d_logits; a.logits_rows = (int)logits_rows; a.logits_sel = d_sel; a.part_val = c->part_val; a.part_idx = c->part_idx;
                 wh_launch_lm_head(s, prec, a);
                 lm_parts = wh_lm_head_parts(prec, a);
             }
@@ -526,7 +539,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     if (use_graph) {
         wh_ctx::StepKey key;
         key.nb = nb; key.n_prompt = P; key.eot = (int)p->eot; key.n_forced = (int)p->n_forced;
-        key.logits_rows = (int)logits_rows; key.d_logits = d_logits;
+        key.logits_rows = (int)logits_rows; key.d_logits = d_logits; key.d_sel = d_sel;
         if (!c->step_exec || !(c->step_key == key)) {
             drop_step_graph(c);   // nothing of it is in flight: every call ends with a stream synchronisation
             c->capturing = true;  // no event records inside the captured step
@@ -591,9 +604,10 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
         for (int i = 0; i < nout[b]; i++) tokens_out[(size_t)b * tok_stride + i] = toks[(size_t)b * ld + i];
     }
     if (logits_out) {
-        for (int b = 0; b < nb; b++) {
+        for (size_t i = 0; i < n_lrows; i++) {
+            const int b = sel ? sel[i] : (int)i;
             const size_t rows = (size_t)nout[b] - P;
-            CTX_HIP(c, hipMemcpy(logits_out + (size_t)b * logits_rows * D.vocab, d_logits + (size_t)b * logits_rows * D.vocab,
+            CTX_HIP(c, hipMemcpy(logits_out + i * logits_rows * D.vocab, d_logits + i * logits_rows * D.vocab,
                                  std::min(rows, logits_rows) * D.vocab * 4, hipMemcpyDeviceToHost));
         }
     }
@@ -860,6 +874,7 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     const size_t o_stk = cv.take(4);
     const size_t o_m1 = cv.take((D.vocab / 32 + 1) * 4), o_m2 = cv.take((D.vocab / 32 + 1) * 4);
     const size_t o_ns = cv.take(B * 4), o_nf = cv.take(B * 4), o_si = cv.take(B * 4), o_fs = cv.take(B * 4), o_gm = cv.take(B * 4);
+    const size_t o_lsel = cv.take(B * 4);
     c->ws_bytes = cv.off;
     hipError_t he = hipMalloc((void**)&c->ws, c->ws_bytes);
     if (he != hipSuccess) { delete c; return wh_fail_hip(he, "hipMalloc(workspace)", __FILE__, __LINE__); }
@@ -885,6 +900,7 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     c->mask_first = (unsigned*)(w + o_m1); c->mask_base = (unsigned*)(w + o_m2);
     c->d_nsamp = (int*)(w + o_ns); c->d_nframes = (int*)(w + o_nf); c->d_src_index = (int*)(w + o_si);
     c->d_frame_start = (int*)(w + o_fs); c->d_gmax = (unsigned*)(w + o_gm);
+    c->logits_sel = (int*)(w + o_lsel);
     // streams: one for everything, or — chip partition — the token loop on `stream` and log-mel + encoder on `s_enc`, each
     // optionally confined to a set of compute units (hipExtStreamCreateWithCUMask: bit i of the mask is compute unit
     // i / 8 of XCD i % 8 on this part, tools/cu_mask_probe.hip)
@@ -929,6 +945,9 @@ void wh_ctx_free(wh_ctx* c) {
     if (c->raw_long) hipFree(c->raw_long);
     if (c->mel_out_long) hipFree(c->mel_out_long);
     if (c->logits) hipFree(c->logits);
+    if (c->s_copy) { hipStreamSynchronize(c->s_copy); hipStreamDestroy(c->s_copy); }
+    if (c->ev_h2d) hipEventDestroy(c->ev_h2d);
+    if (c->pcm2) hipFree(c->pcm2);
     delete c;
 }
 
@@ -1113,6 +1132,28 @@ int wh_decode_greedy_batch(wh_ctx* c, const wh_decode_params* p, int64_t* tokens
     return WH_OK;
 }
 
+int wh_decode_greedy_rows(wh_ctx* c, const wh_decode_params* p, const int32_t* rows, size_t n_rows, int64_t* tokens_out, size_t cap_tokens,
+                          size_t* n_tokens_out, size_t cap_clips, size_t* n_clips_out, float* logits_out, size_t cap_logits_rows) {
+    if (!c) return WH_ERR_ARG;
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    if (!c->have_enc) return fail(c, WH_ERR_STATE, "Missing cached decoder input: encoder states (call wh_transcribe_batch or wh_encode first)");
+    if (c->pre_valid) return fail(c, WH_ERR_STATE, "the resident encoder states belong to a prefetched batch that has not been transcribed yet");
+    const int nb = c->enc_batch;
+    if (n_clips_out) *n_clips_out = (size_t)nb;
+    if (!rows || n_rows == 0 || n_rows > (size_t)nb || !logits_out) return fail(c, WH_ERR_ARG, "wh_decode_greedy_rows: need 1..%d rows and a logits buffer", nb);
+    if (!tokens_out || !n_tokens_out || cap_clips < (size_t)nb || cap_tokens < p->n_prompt + p->max_new_tokens)
+        return fail(c, WH_ERR_ARG, "tokens_out needs %d rows of capacity n_prompt + max_new_tokens", nb);
+    if (cap_logits_rows < p->max_new_tokens) return fail(c, WH_ERR_ARG, "logits_out needs max_new_tokens rows per selected clip");
+    CTX_HIP(c, hipSetDevice(c->m->device));
+    prof_reset(c);
+    const double t0 = now_s();
+    rc = run_decode(c, nb, p, tokens_out, cap_tokens, n_tokens_out, logits_out, cap_logits_rows, nullptr, rows, n_rows);
+    if (rc) return rc;
+    decode_only_timing(c, t0);
+    return WH_OK;
+}
+
 // Clips resident at `pcm` on the device → tokens.  The encoder pass of this batch runs now unless `prefetched`; if
 // `next_pcm` is given, the NEXT batch's log-mel + encoder are put on the encoder stream as soon as this batch's cross-K/V
 // projection has been enqueued, i.e. they run beside this batch's token loop.
@@ -1179,6 +1220,73 @@ int wh_transcribe_batch(wh_ctx* c, const wh_clip* clips, size_t n_clips, const w
     c->timing = wh_timing{};
     c->timing.h2d_s = now_s() - t0;
     return transcribe_resident(c, c->pcm, (int)n_clips, false, nullptr, 0, p, tokens_out, n_tokens_out, t0);
+}
+
+// per-clip checks + counts of a host batch (wh_transcribe_batch*)
+static int host_batch_counts(wh_ctx* c, const wh_clip* clips, size_t n_clips, std::vector<int>& ns, std::vector<int>& nf) {
+    ns.resize(n_clips);
+    nf.resize(n_clips);
+    for (size_t i = 0; i < n_clips; i++) {
+        if (clips[i].n_samples == 0) return fail(c, WH_ERR_EMPTY_AUDIO, "Empty audio");
+        if (!clips[i].pcm) return fail(c, WH_ERR_ARG, "clip %zu: pcm is NULL", i);
+        if (clips[i].n_samples > WH_CLIP_SAMPLES) return fail(c, WH_ERR_ARG, "clip %zu longer than one 30 s window; use wh_transcribe_longform", i);
+        ns[i] = (int)clips[i].n_samples;
+        nf[i] = (int)wh_mel_frames(clips[i].n_samples);
+    }
+    return WH_OK;
+}
+
+int wh_transcribe_batch_next(wh_ctx* c, const wh_clip* clips, size_t n_clips, const wh_clip* next_clips, size_t n_next,
+                             const wh_decode_params* p, int64_t* tokens_out, size_t* n_tokens_out) {
+    if (!c) return WH_ERR_ARG;
+    int rc = check_params(c, p);
+    if (rc) return rc;
+    if (!clips || !tokens_out || !n_tokens_out) return fail(c, WH_ERR_ARG, "NULL argument");
+    if (n_clips == 0 || n_clips > (size_t)c->max_batch) return fail(c, WH_ERR_ARG, "n_clips must be 1..max_batch (%d)", c->max_batch);
+    if (next_clips && (n_next == 0 || n_next > (size_t)c->max_batch)) return fail(c, WH_ERR_ARG, "n_next must be 1..max_batch (%d)", c->max_batch);
+    CTX_HIP(c, hipSetDevice(c->m->device));
+    prof_reset(c);
+    const double t0 = now_s();
+    if (!c->pcm2) {   // second PCM buffer, copy stream and its event: only contexts that use this entry pay for them
+        CTX_HIP(c, hipMalloc((void**)&c->pcm2, (size_t)c->max_batch * WH_CLIP_SAMPLES * 4));
+        CTX_HIP(c, hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking));
+        CTX_HIP(c, hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming));
+    }
+    std::vector<int> ns, nf;
+    rc = host_batch_counts(c, clips, n_clips, ns, nf);
+    if (rc) return rc;
+    rc = enc_begin(c);
+    if (rc) return rc;
+    hipStream_t s = c->s_enc;
+    c->pre_valid = false;
+    // this batch's PCM: already on its way (copied beside the previous call's work), or copied now
+    const bool hit = c->h2d_valid && c->h2d_src == clips[0].pcm && c->h2d_n == (int)n_clips && c->h2d_ns == ns;
+    int buf = hit ? c->h2d_buf : 0;
+    float* d_pcm = buf ? c->pcm2 : c->pcm;
+    c->timing = wh_timing{};
+    if (hit) {
+        CTX_HIP(c, hipStreamWaitEvent(s, c->ev_h2d, 0));
+    } else {
+        if (c->h2d_valid) CTX_HIP(c, hipStreamSynchronize(c->s_copy));   // a prefetch nobody asked for: let it finish before its buffer is reused
+        for (size_t i = 0; i < n_clips; i++)
+            CTX_HIP(c, hipMemcpyAsync(d_pcm + i * WH_CLIP_SAMPLES, clips[i].pcm, clips[i].n_samples * 4, hipMemcpyHostToDevice, s));
+    }
+    c->h2d_valid = false;
+    CTX_HIP(c, hipMemcpyAsync(c->d_nsamp, ns.data(), n_clips * 4, hipMemcpyHostToDevice, s));
+    CTX_HIP(c, hipMemcpyAsync(c->d_nframes, nf.data(), n_clips * 4, hipMemcpyHostToDevice, s));
+    CTX_HIP(c, hipStreamSynchronize(s));
+    c->timing.h2d_s = now_s() - t0;   // (a prefetched batch: what was left of its copy)
+    if (next_clips) {   // the next batch's copy goes to the other buffer on the copy stream, beside everything this call enqueues below
+        std::vector<int> ns2, nf2;
+        rc = host_batch_counts(c, next_clips, n_next, ns2, nf2);
+        if (rc) return rc;
+        float* d_next = buf ? c->pcm : c->pcm2;
+        for (size_t i = 0; i < n_next; i++)
+            CTX_HIP(c, hipMemcpyAsync(d_next + i * WH_CLIP_SAMPLES, next_clips[i].pcm, next_clips[i].n_samples * 4, hipMemcpyHostToDevice, c->s_copy));
+        CTX_HIP(c, hipEventRecord(c->ev_h2d, c->s_copy));
+        c->h2d_buf = buf ^ 1; c->h2d_src = next_clips[0].pcm; c->h2d_n = (int)n_next; c->h2d_ns = ns2; c->h2d_nf = nf2; c->h2d_valid = true;
+    }
+    return transcribe_resident(c, d_pcm, (int)n_clips, false, nullptr, 0, p, tokens_out, n_tokens_out, t0);
 }
 
 int wh_transcribe_batch_device_next(wh_ctx* c, const float* d_pcm, size_t n_clips, const float* d_pcm_next, size_t n_clips_next,

@@ -659,8 +659,10 @@ __global__ __launch_bounds__(256) void k_lm_head(SkinnyArgs a) {
                 const int nn = n + e;
                 const float v = a.ln_part ? wh_ln_fold(acc[t][e], mean, rstd, sv[e], cv[e]) : acc[t][e];
                 if (nn < a.N && m < a.M) {
-                    if (a.logits && gen >= 0 && gen < a.logits_rows)
-                        a.logits[((long)m * a.logits_rows + gen) * a.N + nn] = v;
+                    if (a.logits && gen >= 0 && gen < a.logits_rows) {
+                        const int slot = a.logits_sel ? a.logits_sel[m] : m;
+                        if (slot >= 0) a.logits[((long)slot * a.logits_rows + gen) * a.N + nn] = v;
+                    }
                     const bool sup = (mbits >> e) & 1u;
                     if (!sup && v > bvw[t]) { bvw[t] = v; biw[t] = nn; }  // strict >, NaN never wins
                 }

@@ -532,7 +532,10 @@ __global__ __launch_bounds__(512, 2) void k_lm_head_tile(SkinnyArgs a) {
                 const int nn = n + e;
                 const float v = a.ln_part ? wh_ln_fold(acc[i][j][e], mean, rstd, sv[j][e], cv[j][e]) : acc[i][j][e];
                 if (nn < a.N && m < a.M) {
-                    if (a.logits && gen >= 0 && gen < a.logits_rows) a.logits[((long)m * a.logits_rows + gen) * a.N + nn] = v;
+                    if (a.logits && gen >= 0 && gen < a.logits_rows) {
+                        const int slot = a.logits_sel ? a.logits_sel[m] : m;
+                        if (slot >= 0) a.logits[((long)slot * a.logits_rows + gen) * a.N + nn] = v;
+                    }
                     const bool sup = (mbits[j] >> e) & 1u;
                     if (!sup && v > bv) { bv = v; bi = nn; }  // strict >, columns ascending: lowest index on ties, NaN never wins
                 }

@@ -173,6 +173,16 @@ struct wh_ctx {
     unsigned *mask_first = nullptr, *mask_base = nullptr;
     float* logits = nullptr;    // optional parity buffer (grown on demand)
     size_t logits_cap = 0;
+    int* logits_sel = nullptr;  // [B]: slot of a batch row in `logits` or -1 (wh_decode_greedy_rows)
+    // wh_transcribe_batch_next: the next batch's PCM copied to a second device buffer on a copy stream beside this batch's work
+    float* pcm2 = nullptr;      // [B][480000], allocated at the first call of that entry
+    hipStream_t s_copy = nullptr;
+    hipEvent_t ev_h2d = nullptr;
+    int h2d_buf = 0;            // buffer (0: pcm, 1: pcm2) that holds / will hold the prefetched batch
+    const float* h2d_src = nullptr;   // host address of the prefetched batch's first clip
+    int h2d_n = 0;
+    bool h2d_valid = false;
+    std::vector<int> h2d_ns, h2d_nf;  // its per-clip sample / frame counts
     int tok_ld = 0;
     int mpad = 16;              // row pitch of the k-slab-major decode activations (multiple of 16)
     int cross_splits = 1;
@@ -182,9 +192,10 @@ struct wh_ctx {
     struct StepKey {
         int nb = 0, n_prompt = 0, eot = 0, n_forced = 0, logits_rows = 0;
         const float* d_logits = nullptr;
+        const int* d_sel = nullptr;
         bool operator==(const StepKey& o) const {
             return nb == o.nb && n_prompt == o.n_prompt && eot == o.eot && n_forced == o.n_forced && logits_rows == o.logits_rows &&
-                   d_logits == o.d_logits;
+                   d_logits == o.d_logits && d_sel == o.d_sel;
         }
     } step_key;
     hipGraph_t step_graph = nullptr;

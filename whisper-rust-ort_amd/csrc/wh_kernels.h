@@ -96,8 +96,9 @@ struct SkinnyArgs {
     int n_prompt = 0;
     const unsigned* mask_first = nullptr;
     const unsigned* mask_base = nullptr;
-    float* logits = nullptr;   // optional [M][logits_rows][N]
+    float* logits = nullptr;   // optional [M][logits_rows][N], or — logits_sel given — [selected][logits_rows][N]
     int logits_rows = 0;
+    const int* logits_sel = nullptr;   // [M]: slot of row m in `logits`, -1 = this row's logits are not kept
     float* part_val = nullptr;
     int* part_idx = nullptr;
 };

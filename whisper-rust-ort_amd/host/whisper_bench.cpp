@@ -40,6 +40,7 @@ struct Args {
     int streams_per_gpu = 1;        // contexts (HIP streams) per device, one host thread each
     int load_threads = 0;           // host threads that decode / synthesise audio ahead of the GPU (0 = min(16, cores))
     std::string precision = "bf16";
+    bool print_plan = false;   // --print-plan: print the device -> context plan of this command line and exit before any device is touched
     size_t synthetic_clips = 0;
     uint64_t seed = 1000;
 };
@@ -78,13 +79,14 @@ static bool parse_args(int argc, char** argv, Args& a) {
         std::string v;
         if (k == "--write-txt") a.write_txt = true;
         else if (k == "--timestamps") a.timestamps = true;
+        else if (k == "--print-plan") a.print_plan = true;
         else if (k == "--help" || k == "-h") {
             printf("Usage: whisper_bench [--audio-dir DIR] [--model-id ID] [--onnx-dir DIR|synthetic:<preset>:<seed>] [--language en] "
                    "[--task transcribe] [--max-new-tokens 128] [--warmup 0] [--limit-files 0] [--discovery-best-json F] "
                    "[--out-csv F] [--out-json F] [--out-summary-json F] [--intra-op N] [--inter-op N] [--write-txt] "
                    "[--tokenizer-json F] [--timestamps] [--chunk-parallelism N] [--chunk-length-s 30] [--overlap-s 5] "
                    "[--device 0] [--devices 0-7] [--streams-per-gpu 1] [--load-threads N] [--precision bf16|f32|fp8|f16x3] [--max-batch 16] "
-                   "[--synthetic-clips N] [--seed 1000]\n");
+                   "[--synthetic-clips N] [--seed 1000] [--print-plan]\n");
             exit(0);
         } else {
             if (!need(i, argv[i], v, inl)) return false;
@@ -333,6 +335,23 @@ int main(int argc, char** argv) {
         // `--streams-per-gpu` contexts per model, one host thread per context; files are independent units
         // (src/main.rs:1164 loops over them serially) and are dealt to whichever context is free.
         const std::vector<int> devices = parse_devices(a.devices, a.device);
+        if (a.print_plan) {   // what the command line asks for, before wh_model_load touches a device (CPU test of the --devices surface)
+            JVal plan = JVal::obj(false);
+            std::string devs = "[", ctxl = "[";
+            for (size_t i = 0; i < devices.size(); i++) {
+                devs += (i ? ", " : "") + std::to_string(devices[i]);
+                for (int st = 0; st < a.streams_per_gpu; st++)
+                    ctxl += std::string(ctxl.size() > 1 ? ", " : "") + "{\"context\": " + std::to_string(i * a.streams_per_gpu + st) + ", \"device\": " + std::to_string(devices[i]) +
+                            ", \"stream\": " + std::to_string(st) + "}";
+            }
+            JVal jd; jd.raw = devs + "]";
+            JVal jc; jc.raw = ctxl + "]";
+            plan.set("devices", jd).set("models", JVal::integer((long long)devices.size())).set("contexts", jc)
+                .set("host_threads", JVal::integer((long long)(devices.size() * a.streams_per_gpu))).set("max_batch", JVal::integer(a.max_batch))
+                .set("precision", JVal::str(a.precision));
+            printf("%s\n", plan.pretty().c_str());
+            return 0;
+        }
         std::vector<wh_model*> models;
         std::vector<wh_ctx*> ctxs;
         for (int dev : devices) {
