@@ -290,7 +290,7 @@ def test_argmax_edge_cases_via_suppress_all_but_one(gpu):
 # Measured on MI355X with the encoder LayerNorm fold: encoder states 0.070 (micro) / 0.081 (base), logits 0.080 (micro) / 0.132 (base) on
 # logits of sigma 1.3; a token is "decided" where the f32 top-1 margin exceeds twice the logit bound — there the argmax must agree.
 BF16_ENC_BOUND, BF16_LOGIT_BOUND = 0.10, 0.16
-BF16_MIN_DECIDED = {"micro": 1, "base": 1}   # steps of the 24-step golden history whose f32 top-1 margin exceeds 2 x the logit bound
+BF16_MIN_DECIDED = {"micro": 4, "base": 3}   # measured 5 and 4   # steps of the 24-step golden history whose f32 top-1 margin exceeds 2 x the logit bound
 
 
 @pytest.mark.parametrize("preset,seed,clip", [("micro", 11, 2), ("base", 1234, 0)])
@@ -516,7 +516,7 @@ def test_f32_base_batched_contexts_match_golden(gpu, golden_dir, nb, prec_name):
     assert worst <= LOGIT_TOL
 
 
-@pytest.mark.parametrize("prec_name", ["bf16", "fp8"])
+@pytest.mark.parametrize("prec_name", ["bf16", "fp8", "f16x3"])
 def test_wide_batch_decode_gemm_is_bit_identical(gpu, monkeypatch, prec_name):
     """k_dec_gemm_wide (several 16-column tiles per workgroup) and k_lm_head_tile (the LM head on 256 x 256 LDS-DMA tiles), both
     chosen from the batch size, against k_dec_gemm / k_lm_head on the same 512-clip context: same K split, same summation

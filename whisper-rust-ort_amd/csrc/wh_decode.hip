@@ -1360,7 +1360,7 @@ void launch_lm_head_t(hipStream_t s, const SkinnyArgs& a, int* n_parts_out = nul
 // a.X = final-LayerNorm'ed rows [M][K] in the compute dtype
 void wh_launch_lm_head(hipStream_t s, int prec, const SkinnyArgs& a) {
     if (prec == WH_PREC_F32) launch_lm_head_t<float>(s, a);
-    else if (prec == WH_PREC_F16X3) launch_lm_head_t<h2>(s, a);
+    else if (prec == WH_PREC_F16X3) { if (wh_lm_head_tile_x3_applicable(a)) wh_launch_lm_head_tile_x3(s, a); else launch_lm_head_t<h2>(s, a); }
     else if (wh_lm_head_tile_applicable(a)) wh_launch_lm_head_tile(s, a);   // hundreds of rows: 256 x 256 tiles (wh_gemm8.hip), same logits
     else launch_lm_head_t<bf16>(s, a);
 }
@@ -1368,7 +1368,8 @@ void wh_launch_lm_head(hipStream_t s, int prec, const SkinnyArgs& a) {
 // number of argmax partials per row the LM head writes for this shape (its layout is [part][x_mpad])
 int wh_lm_head_parts(int prec, const SkinnyArgs& a) {
     int n = 0;
-    if (prec == WH_PREC_F32 || prec == WH_PREC_F16X3) launch_lm_head_t<float>(nullptr, a, &n);
+    if (prec == WH_PREC_F16X3 && wh_lm_head_tile_x3_applicable(a)) n = wh_lm_head_tile_x3_parts(a);
+    else if (prec == WH_PREC_F32 || prec == WH_PREC_F16X3) launch_lm_head_t<float>(nullptr, a, &n);
     else if (wh_lm_head_tile_applicable(a)) n = wh_lm_head_tile_parts(a);
     else launch_lm_head_t<bf16>(nullptr, a, &n);
     return n;

@@ -202,6 +202,185 @@ __global__ __launch_bounds__(512, 2) void k_gemm8x(GemmArgs g) {
     }
 }
 
+
+// ---- the LM head at hundreds of rows, WH_PREC_F16X3: k_lm_head_tile's contract (wh_gemm8.hip) on this file's main loop ----------------------
+// logits = LN(x) . E^T over the whole vocabulary + masked argmax partials (reference argmax_last_dim_raw, src/main.rs:709-735).  A workgroup
+// owns a 256 x 256 logit tile; the activation rows come from the decode slab layout [K/32][mpad][32] h2 (a k-step's 256 rows are 256
+// consecutive 128-byte blocks), the tied embedding with the final LayerNorm's gamma folded in is the weight operand.  Same MFMA chain over k
+// as k_lm_head<h2> (three fp16 MFMAs per k-step in mma16's order, one accumulator), LayerNorm partial sums reduced in the same order, the
+// same epilogue expression: logits bit-identical, so the launcher may pick by the call's row count.
+__global__ __launch_bounds__(512, 2) void k_lm_head_tile_x3(SkinnyArgs a) {
+    extern __shared__ __attribute__((aligned(128))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int fl = lane & 15, fg = lane >> 4;
+    const int nk = a.K / BK;
+    const int nbn = (a.N + BN - 1) / BN;
+    const int total = nbn * ((a.M + BM - 1) / BM);
+    int tile = blockIdx.x;
+    {
+        const int q = total >> 3, r = total & 7, xcd = tile & 7, idx = tile >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int ct = tile % nbn, m0 = (tile / nbn) * BM, n0 = ct * BN;
+
+    // final LayerNorm: quarter sums of the producer's per-tile partials, two quarters per thread (row tid & 255)
+    float* lnstat = reinterpret_cast<float*>(smem + (size_t)NSLOT * SLOT);   // [256][2] mean, rstd
+    float* lnq = lnstat + 2 * BM;                                            // [4][256][2]
+    if (a.ln_part) {
+        const int r = tid & (BM - 1), h = tid >> 8, row = min(m0 + r, a.x_mpad - 1);
+        float s1a, s2a, s1b, s2b;
+        ln_partial_sum(a.ln_part, a.ln_tiles, a.x_mpad, row, h, 4, s1a, s2a);
+        ln_partial_sum(a.ln_part, a.ln_tiles, a.x_mpad, row, h + 2, 4, s1b, s2b);
+        lnq[(h * BM + r) * 2] = s1a;
+        lnq[(h * BM + r) * 2 + 1] = s2a;
+        lnq[((h + 2) * BM + r) * 2] = s1b;
+        lnq[((h + 2) * BM + r) * 2 + 1] = s2b;
+    }
+
+    const int rl = lane >> 3, ps = lane & 7;
+    const char* a_src[4];
+    const char* w_src[4];
+    const long a_kstep = (long)a.x_mpad * ROWB;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int row = wave * 32 + j * 8 + rl;
+        a_src[j] = reinterpret_cast<const char*>(a.X) + (long)min(m0 + row, a.x_mpad - 1) * ROWB + ((ps ^ swz(row)) << 4);
+        w_src[j] = reinterpret_cast<const char*>(a.W) + (long)min(n0 + row, a.N - 1) * a.K * 4 + ((ps ^ swz(row)) << 4);
+    }
+    auto stage = [&](int slot, int kt) {
+        char* base = smem + slot * SLOT;
+#pragma unroll
+        for (int j = 0; j < 4; j++) glds16(a_src[j] + kt * a_kstep, base + (wave * 32 + j * 8) * ROWB);
+#pragma unroll
+        for (int j = 0; j < 4; j++) glds16(w_src[j] + (long)kt * ROWB, base + SLOT_A + (wave * 32 + j * 8) * ROWB);
+    };
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0, 0, 0, 0};
+    const int ch_hi = (fg ^ swz(fl)) << 4, ch_lo = ((4 + fg) ^ swz(fl)) << 4;
+    const int a_row = (wm * (TM * 16) + fl) * ROWB, w_row = SLOT_A + (wn * (TN * 16) + fl) * ROWB;
+    auto frag = [&](const char* sb, int row_off) {
+        xfrag f;
+        f.hi = *reinterpret_cast<const f16x8*>(sb + row_off + ch_hi);
+        f.lo = *reinterpret_cast<const f16x8*>(sb + row_off + ch_lo);
+        return f;
+    };
+    stage(0, 0);
+    for (int kt = 0; kt < nk; kt++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (first step: this wave's quarter sums have left for LDS)
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        if (kt == 0 && a.ln_part && tid < BM) {   // the quarter sums are in LDS since the barrier above
+            const float s1 = (lnq[tid * 2] + lnq[(BM + tid) * 2]) + (lnq[(2 * BM + tid) * 2] + lnq[(3 * BM + tid) * 2]);
+            const float s2 = (lnq[tid * 2 + 1] + lnq[(BM + tid) * 2 + 1]) + (lnq[(2 * BM + tid) * 2 + 1] + lnq[(3 * BM + tid) * 2 + 1]);
+            float mean, rstd;
+            wh_ln_mean_rstd(s1, s2, (float)a.K, false, mean, rstd);
+            lnstat[2 * tid] = mean;
+            lnstat[2 * tid + 1] = rstd;
+        }
+        const char* sb = smem + (kt & 1) * SLOT;
+        xfrag wf[TN];
+#pragma unroll
+        for (int j = 0; j < TN; j++) wf[j] = frag(sb, w_row + j * 16 * ROWB);
+#pragma unroll
+        for (int i0 = 0; i0 < TM; i0 += 2) {
+            xfrag af[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) af[u] = frag(sb, a_row + (i0 + u) * 16 * ROWB);
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) mma16(acc[i0 + u][j], wf[j], af[u]);
+        }
+    }
+    __syncthreads();   // lnstat visible to everyone; the ring is idle
+
+    // ---- epilogue: final LayerNorm fold + masked argmax, one partial per (column tile, row) ----------------------------------------------
+    const int pos = *a.pos_p;
+    const int gen = pos - (a.n_prompt - 1);
+    const unsigned* mask = (gen == 0) ? a.mask_first : a.mask_base;
+    const int nw0 = n0 + wn * 64;
+    float sv[TN][4], cv[TN][4];
+    unsigned mbits[TN];
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = nw0 + j * 16 + 4 * fg;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { sv[j][e] = 0.0f; cv[j][e] = 0.0f; }
+        if (a.ln_part) {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (n + e < a.N) { sv[j][e] = a.ln_s[n + e]; cv[j][e] = a.bias[n + e]; }
+        }
+        mbits[j] = 0;
+        if (n < a.N) mbits[j] = mask[n >> 5] >> (n & 31);
+    }
+    float* red_v = reinterpret_cast<float*>(smem);            // [4][256]
+    int* red_i = reinterpret_cast<int*>(smem) + WN * BM;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int rloc = wm * (TM * 16) + i * 16 + fl, m = m0 + rloc;
+        const float mean = a.ln_part ? lnstat[2 * rloc] : 0.0f, rstd = a.ln_part ? lnstat[2 * rloc + 1] : 1.0f;
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = nw0 + j * 16 + 4 * fg;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int nn = n + e;
+                const float v = a.ln_part ? wh_ln_fold(acc[i][j][e], mean, rstd, sv[j][e], cv[j][e]) : acc[i][j][e];
+                if (nn < a.N && m < a.M) {
+                    if (a.logits && gen >= 0 && gen < a.logits_rows) {
+                        const int slot = a.logits_sel ? a.logits_sel[m] : m;
+                        if (slot >= 0) a.logits[((long)slot * a.logits_rows + gen) * a.N + nn] = v;
+                    }
+                    const bool sup = (mbits[j] >> e) & 1u;
+                    if (!sup && v > bv) { bv = v; bi = nn; }  // strict >, columns ascending: lowest index on ties, NaN never wins
+                }
+            }
+        }
+        wh_u32x2 tv = __builtin_amdgcn_permlane16_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+        wh_u32x2 ti = __builtin_amdgcn_permlane16_swap((unsigned)bi, (unsigned)bi, false, false);
+        float v0 = __uint_as_float(tv.x), v1 = __uint_as_float(tv.y);
+        int i0 = (int)ti.x, i1 = (int)ti.y;
+        bool take1 = v1 > v0 || (v1 == v0 && i1 < i0);
+        bv = take1 ? v1 : v0;
+        bi = take1 ? i1 : i0;
+        tv = __builtin_amdgcn_permlane32_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+        ti = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
+        v0 = __uint_as_float(tv.x); v1 = __uint_as_float(tv.y);
+        i0 = (int)ti.x; i1 = (int)ti.y;
+        take1 = v1 > v0 || (v1 == v0 && i1 < i0);
+        bv = take1 ? v1 : v0;
+        bi = take1 ? i1 : i0;
+        if (fg == 0) {
+            red_v[wn * BM + rloc] = bv;
+            red_i[wn * BM + rloc] = bi;
+        }
+    }
+    __syncthreads();
+    if (tid < BM && m0 + tid < a.M) {
+        float bv = red_v[tid];
+        int bi = red_i[tid];
+#pragma unroll
+        for (int w = 1; w < WN; w++) {
+            const float v1 = red_v[w * BM + tid];
+            const int i1 = red_i[w * BM + tid];
+            const bool take1 = v1 > bv || (v1 == bv && i1 < bi);
+            bv = take1 ? v1 : bv;
+            bi = take1 ? i1 : bi;
+        }
+        a.part_val[(long)ct * a.x_mpad + m0 + tid] = bv;
+        a.part_idx[(long)ct * a.x_mpad + m0 + tid] = bi;
+    }
+}
+
 template <typename TO>
 void launch8x(hipStream_t s, const GemmArgs& g) {
     const size_t sm = (size_t)NSLOT * SLOT;
@@ -214,10 +393,10 @@ void launch8x(hipStream_t s, const GemmArgs& g) {
 }  // namespace
 
 // h2 operands: every row start 128-byte aligned (lda, ldw, a_bs multiples of 32 elements), K a multiple of 32; h2 outputs need column groups
-// of 8 inside one 32-block (ldc, c_bs, c_ns multiples of 32; N % 8 == 0)
+// of 8 (a last one of 4) inside one 32-block (ldc, c_bs, c_ns multiples of 32)
 bool wh_gemm8x_applicable(const GemmArgs& g, bool out_h2) {
     const bool rows_ok = (g.lda % 32) == 0 && (g.ldw % 32) == 0 && (g.a_bs % 32) == 0 && (g.a_zs % 32) == 0 && (g.w_zs % 32) == 0;
-    const bool out_ok = !out_h2 || ((g.ldc % 32) == 0 && (g.c_bs % 32) == 0 && (g.c_ns % 32) == 0 && (g.c_zs % 32) == 0 && (g.N % 8) == 0);
+    const bool out_ok = !out_h2 || ((g.ldc % 32) == 0 && (g.c_bs % 32) == 0 && (g.c_ns % 32) == 0 && (g.c_zs % 32) == 0);   // (N % 4 == 0: a last group of four columns)
     return g.M >= BM && g.N >= 128 && (g.K % BK) == 0 && (g.N % 4) == 0 && (g.n_per >= g.N || (g.n_per % 64) == 0) && g.m_per >= 8 && rows_ok && out_ok &&
            !g.wscale && !g.ln_mode && !g.xb_out && !g.stats_out;
 }
@@ -230,4 +409,18 @@ int wh_launch_gemm8x(hipStream_t s, bool out_h2, const GemmArgs& g) {
     if (out_h2) launch8x<h2>(s, g);
     else launch8x<float>(s, g);
     return WH_OK;
+}
+
+// LM head at hundreds of rows, h2 operands: one argmax partial per (256-column tile, row) — layout [part][x_mpad]
+bool wh_lm_head_tile_x3_applicable(const SkinnyArgs& a) {
+    const char* e = getenv("WH_LM_TILE_MIN_ROWS");   // (0 disables: A/B runs and the parity test flip it between contexts)
+    const int min_rows = e ? atoi(e) : 256;
+    return min_rows > 0 && a.M >= min_rows && (a.K % BK) == 0 && a.X != nullptr && a.xpart == nullptr && a.wscale == nullptr;
+}
+int wh_lm_head_tile_x3_parts(const SkinnyArgs& a) { return (a.N + BN - 1) / BN; }
+void wh_launch_lm_head_tile_x3(hipStream_t s, const SkinnyArgs& a) {
+    const size_t sm = (size_t)NSLOT * SLOT + (size_t)BM * 2 * 4 * 5;   // ring + LayerNorm statistics ([256][2] + four quarter sums)
+    dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM));
+    wh_ensure_dyn_lds((const void*)k_lm_head_tile_x3, sm);
+    hipLaunchKernelGGL(k_lm_head_tile_x3, grid, dim3(512), sm, s, a);
 }

@@ -174,6 +174,10 @@ void wh_launch_lm_head(hipStream_t s, int prec, const SkinnyArgs& a);
 bool wh_lm_head_tile_applicable(const SkinnyArgs& a);
 int wh_lm_head_tile_parts(const SkinnyArgs& a);
 void wh_launch_lm_head_tile(hipStream_t s, const SkinnyArgs& a);
+// wh_gemm8x.hip: the same for WH_PREC_F16X3 (h2 operands)
+bool wh_lm_head_tile_x3_applicable(const SkinnyArgs& a);
+int wh_lm_head_tile_x3_parts(const SkinnyArgs& a);
+void wh_launch_lm_head_tile_x3(hipStream_t s, const SkinnyArgs& a);
 int wh_lm_head_parts(int prec, const SkinnyArgs& a);  // argmax partials per row written by wh_launch_lm_head, layout [part][x_mpad]
 void wh_launch_argmax_finish(hipStream_t s, int prec, const float* part_val, const int* part_idx, int n_parts, int mpad, int* pos_p,
                              int* ticket, const DecodeState& st, int B, const NextEmbed& ne);
