@@ -399,6 +399,11 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
     // (c->lnpart); the GEMM that consumes LN(x) has γ folded into its weights and applies mean / rstd in
     // its epilogue (wh_model.cpp fold_ln).
     const int ln_tiles_d = (int)(d / 16);
+    // the decode GEMMs: tile GEMMs on contexts of a thousand clips and more (a property of the context, never of the call)
+    auto dec_gemm = [&](bool out_f32, const SkinnyArgs& ga) {
+        if (c->dec_tile && wh_dec_tile_applicable(prec, ga)) wh_launch_dec_tile(s, prec, out_f32, ga);
+        else wh_launch_dec_gemm(s, prec, out_f32, ga);
+    };
     // `embed_first`: this step embeds its own input token; false when the previous step's argmax finish already did
     int lm_parts = 0;
     auto launch_step = [&](bool emits, bool embed_first) {
@@ -416,7 +421,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 a.X = c->dxs; a.x_mpad = mpad; a.W = L.qkv_w; a.bias = L.qkv_b; a.wscale = L.qkv_sc; a.C = c->dqkv; a.ldc = 3 * d;
                 a.M = nb; a.N = (int)(3 * d); a.K = (int)d;
                 a.ln_part = c->lnpart; a.ln_tiles = (l == 0) ? 1 : ln_tiles_d; a.ln_s = L.qkv_s;
-                wh_launch_dec_gemm(s, prec, false, a);
+                dec_gemm(false, a);
             }
             {
                 Prof pr(c, WH_KG_DEC_OTHER);
@@ -430,7 +435,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 a.X = c->datt; a.x_mpad = mpad; a.W = L.o_w; a.bias = L.o_b; a.wscale = L.o_sc; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
                 a.M = nb; a.N = (int)d; a.K = (int)d; a.xslab_out = c->dxs; a.stats_out = c->lnpart;
                 if (f8) a.xgamma = L.ln2_w;
-                wh_launch_dec_gemm(s, prec, true, a);
+                dec_gemm(true, a);
             }
             if (c->cross_es) {
                 // the attention runs on the encoder states (wh_cross_es.hip): W_k moves to the query side, W_v behind the attention
@@ -439,7 +444,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                     a = SkinnyArgs();
                     a.X = c->dxs; a.x_mpad = mpad; a.W = L.cq_w; a.bias = L.cq_b; a.C = c->dq32; a.ldc = d; a.M = nb; a.N = (int)d; a.K = (int)d;
                     a.ln_part = c->lnpart; a.ln_tiles = ln_tiles_d; a.ln_s = L.cq_s;
-                    wh_launch_dec_gemm(s, prec, true, a);
+                    dec_gemm(true, a);
                     // expanded queries qe[h] = W_k,h^T q_h: [nb][H][d] f32
                     wh_launch_dec_qexpand(s, prec, c->dq32, L.cqx_w, c->dqe, nb, (int)d, D.n_heads);
                 }
@@ -454,7 +459,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                     a.M = nb; a.N = WH_HEAD_DIM; a.K = (int)d;
                     a.zn = D.n_heads; a.x_zs = (long)(d / 32) * mpad * 32; a.w_zs = (long)WH_HEAD_DIM * d; a.c_zs = (long)(WH_HEAD_DIM / 32) * mpad * 32;
                     a.bias_zs = WH_HEAD_DIM;
-                    wh_launch_dec_gemm(s, prec, false, a);
+                    dec_gemm(false, a);
                 }
             } else {
             {   // LN2 ∘ cross-attention query
@@ -462,7 +467,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 a = SkinnyArgs();
                 a.X = c->dxs; a.x_mpad = mpad; a.W = L.cq_w; a.bias = L.cq_b; a.wscale = L.cq_sc; a.C = c->dq; a.ldc = d; a.M = nb; a.N = (int)d; a.K = (int)d;
                 a.ln_part = c->lnpart; a.ln_tiles = ln_tiles_d; a.ln_s = L.cq_s;
-                wh_launch_dec_gemm(s, prec, false, a);
+                dec_gemm(false, a);
             }
             {
                 Prof pr(c, WH_KG_DEC_CROSS_ATTN);
@@ -484,7 +489,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 a.x_mpad = mpad; a.W = L.co_w; a.bias = L.co_b; a.wscale = L.co_sc; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
                 a.M = nb; a.N = (int)d; a.K = (int)d; a.xslab_out = c->dxs; a.stats_out = c->lnpart;
                 if (f8) a.xgamma = L.ln3_w;
-                wh_launch_dec_gemm(s, prec, true, a);
+                dec_gemm(true, a);
             }
             {   // LN3 ∘ fc1 + GELU (slab output)
                 Prof pr(c, WH_KG_DEC_GEMM);
@@ -492,7 +497,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 a.X = c->dxs; a.x_mpad = mpad; a.W = L.fc1_w; a.bias = L.fc1_b; a.wscale = L.fc1_sc; a.act = 1; a.C = c->dh; a.c_mpad = mpad;
                 a.M = nb; a.N = (int)F; a.K = (int)d;
                 a.ln_part = c->lnpart; a.ln_tiles = ln_tiles_d; a.ln_s = L.fc1_s;
-                wh_launch_dec_gemm(s, prec, false, a);
+                dec_gemm(false, a);
             }
             {   // fc2 + residual → x, raw slab, partials for the next layer's LN1 / the final LN
                 Prof pr(c, WH_KG_DEC_GEMM);
@@ -501,7 +506,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 a.M = nb; a.N = (int)d; a.K = (int)F; a.xslab_out = c->dxs; a.stats_out = c->lnpart;
                 if (f8) a.xgamma = (l + 1 < D.dec_layers) ? m->dec[l + 1].ln1_w : m->dec_ln_w;  // next consumer's LayerNorm
                 if (!emits && l == D.dec_layers - 1) { a.ticket = c->step_ticket; a.pos_w = c->pos; }  // prompt position: advance here
-                wh_launch_dec_gemm(s, prec, true, a);
+                dec_gemm(true, a);
             }
         }
         if (emits) {  // final LN ∘ tied LM head + masked argmax; the finish kernel advances the position
@@ -835,6 +840,12 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
         wh_set_error("wh_ctx_create_ex: WH_CTX_CROSS_ES_ON needs a bf16 or f16x3 model of whisper-base geometry (d_model 512, 8 heads)");
         return WH_ERR_UNSUPPORTED;
     }
+    // decode GEMMs on LDS-DMA tiles (wh_dec_tile.hip) where a batch is a thousand rows and more, in the split-fp16 mode: measured against
+    // k_dec_gemm_wide at 2048 clips — f16x3 224 -> 193 ms of decode GEMMs per step; bf16 130 -> 133 ms (both forms sit
+    // on the per-CU L2 -> LDS rate there: 256 KB of operands per 128 x 128 tile), so bf16 keeps k_dec_gemm_wide.  WH_DEC_TILE=0 / 1 forces
+    // it off / on for A/B runs
+    c->dec_tile = m->prec == WH_PREC_F16X3 && max_batch >= 1024;
+    if (const char* e = getenv("WH_DEC_TILE")) c->dec_tile = (m->prec == WH_PREC_BF16 || m->prec == WH_PREC_F16X3) && atoi(e) != 0;
     // rows from one clip's encoder states to the next: 20 rows (20 KiB) of padding, so that the lock-step streams of the persistent
     // workgroups (clip i, i + 256, ...) do not all sit on the same 4 KiB phase of the 1,536,000-byte clip pitch: 491 -> 480-485 us per
     // 2048-clip launch (tools/es_state_probe.py, WH_ES_PAD = 0 / 12 / 20 / 28 / 44 / 84: 491 / 487 / 482 / 484 / 485 / 490)

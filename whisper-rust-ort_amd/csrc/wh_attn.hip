@@ -273,6 +273,7 @@ void wh_launch_enc_attn(hipStream_t s, int prec, const void* qk, const void* vT,
         wh_ensure_dyn_lds((const void*)k_enc_attn<float, 4>, sm);
         hipLaunchKernelGGL((k_enc_attn<float, 4>), grid, dim3(256), sm, s, (const float*)qk, (const float*)vT, (float*)out, S, d, ldv, n_heads);
     } else if (prec == WH_PREC_F16X3) {   // Q, K, V^T and the output as fp16 limb pairs (h2); the probabilities are split in registers
+        // (4 waves, two workgroups per CU; the 8-wave form that pays in bf16 measured 190 vs 185 ms per 2048-clip step here)
         dim3 grid(((S + 127) / 128) * n_heads * n_clips);
         const size_t sm = (size_t)2 * 2 * 64 * (64 + 8) * 4;
         wh_ensure_dyn_lds((const void*)k_enc_attn<h2, 4>, sm);

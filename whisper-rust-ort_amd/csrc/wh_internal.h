@@ -186,6 +186,8 @@ struct wh_ctx {
     int tok_ld = 0;
     int mpad = 16;              // row pitch of the k-slab-major decode activations (multiple of 16)
     int cross_splits = 1;
+    // the decode GEMMs as LDS-DMA tile GEMMs (wh_dec_tile.hip): decided at creation from the model and the context's capacity
+    bool dec_tile = false;
     // The captured decode step, kept across calls: every kernel argument the step bakes in is either a fixed workspace
     // address or one of the values below, so a call with the same key replays the instantiated graph as it is.
     // Destroyed in wh_ctx_free (after the stream has drained) or when the key changes.

@@ -167,6 +167,10 @@ void wh_launch_enc_attn(hipStream_t s, int prec, const void* qk, const void* vT,
                         int n_heads, int ldv);
 
 void wh_launch_dec_gemm(hipStream_t s, int prec, bool out_f32, const SkinnyArgs& a);
+// wh_dec_tile.hip: the same contract on 128 x {128, 64} LDS-DMA tiles for contexts of a thousand clips and more (bf16 / f16x3 operands; not
+// bit-identical to k_dec_gemm, so chosen per context: wh_ctx::dec_tile)
+bool wh_dec_tile_applicable(int prec, const SkinnyArgs& a);
+void wh_launch_dec_tile(hipStream_t s, int prec, bool out_f32, const SkinnyArgs& a);
 void wh_launch_dec_embed(hipStream_t s, int prec, const void* tok_emb, const float* pos_emb, const int* feed, int feed_ld,
                          const int* pos_p, float* x, void* xslab, float* stats, int rows, int d, int mpad, const float* xgamma);
 void wh_launch_lm_head(hipStream_t s, int prec, const SkinnyArgs& a);
