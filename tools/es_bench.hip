@@ -29,9 +29,9 @@ int main(int argc, char** argv) {
     hipMalloc((void**)&wh_es_bench_dbg, 64 * 8);
     hipMemset(wh_es_bench_dbg, 0, 64 * 8);
     for (int nt = 1; nt >= 0; nt--) {
-        for (int i = 0; i < 3; i++) wh_launch_dec_cross_attn_es(s, WH_PREC_BF16, q, E, out, S, S, B, mpad, nt);
+        for (int i = 0; i < 3; i++) wh_launch_dec_cross_attn_es(s, WH_PREC_BF16, q, E, out, S, S, B, mpad, nt, 256);
         hipEventRecord(e0, s);
-        for (int i = 0; i < reps; i++) wh_launch_dec_cross_attn_es(s, WH_PREC_BF16, q, E, out, S, S, B, mpad, nt);
+        for (int i = 0; i < reps; i++) wh_launch_dec_cross_attn_es(s, WH_PREC_BF16, q, E, out, S, S, B, mpad, nt, 256);
         hipEventRecord(e1, s);
         hipStreamSynchronize(s);
         float ms = 0; hipEventElapsedTime(&ms, e0, e1);

@@ -89,8 +89,8 @@ void prof_collect(wh_ctx* c) {
         double ms = 0;
         for (size_t i = 0; i < c->prof_used[g]; i++) {
             float t = 0;
-            hipEventElapsedTime(&t, c->prof_events[g][i].first, c->prof_events[g][i].second);
-            ms += t;
+            // (events of a prefetched encoder pass may still be pending on the encoder stream: hipErrorNotReady — not counted)
+            if (hipEventElapsedTime(&t, c->prof_events[g][i].first, c->prof_events[g][i].second) == hipSuccess) ms += t;
         }
         c->prof_ms[g] = ms;
     }
@@ -450,7 +450,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 }
                 {
                     Prof pr(c, WH_KG_DEC_CROSS_ATTN);
-                    wh_launch_dec_cross_attn_es(s, prec, c->dqe, c->es_E, c->dctx, (int)S, c->es_rows, nb, mpad, kv_nt);
+                    wh_launch_dec_cross_attn_es(s, prec, c->dqe, c->es_E, c->dctx, (int)S, c->es_rows, nb, mpad, kv_nt, c->dec_cus);
                 }
                 {   // per head: W_v,h ctx_h + b_v,h → the attention output the out-projection below expects (slab layout)
                     Prof pr(c, WH_KG_DEC_GEMM);
@@ -806,6 +806,7 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     auto* c = new wh_ctx();
     c->m = m;
     c->max_batch = max_batch;
+    c->dec_cus = dec_masked ? (int)mask_bits(opts->dec_cu_mask, opts->dec_cu_mask_words) : n_cus;   // compute units the token-loop stream may use
     c->no_graph = getenv("WH_NO_GRAPH") != nullptr;
     c->sync_every_pos = getenv("WH_SYNC_EVERY_POS") != nullptr;
     const wh_dims& D = m->dims;
@@ -1110,6 +1111,7 @@ int wh_decode_greedy(wh_ctx* c, const wh_decode_params* p, int64_t* tokens_out, 
     int rc = check_params(c, p);
     if (rc) return rc;
     if (!c->have_enc) return fail(c, WH_ERR_STATE, "Missing cached decoder input: encoder states (call wh_encode first)");
+    if (c->pre_valid) return fail(c, WH_ERR_STATE, "the resident encoder states belong to a prefetched batch that has not been transcribed yet");
     if (!tokens_out || !n_tokens_out || cap_tokens < p->n_prompt + p->max_new_tokens)
         return fail(c, WH_ERR_ARG, "tokens_out needs capacity n_prompt + max_new_tokens");
     if (logits_out && cap_logits_rows < p->max_new_tokens) return fail(c, WH_ERR_ARG, "logits_out needs max_new_tokens rows");
@@ -1169,14 +1171,15 @@ int wh_decode_greedy_rows(wh_ctx* c, const wh_decode_params* p, const int32_t* r
 // `next_pcm` is given, the NEXT batch's log-mel + encoder are put on the encoder stream as soon as this batch's cross-K/V
 // projection has been enqueued, i.e. they run beside this batch's token loop.
 static int transcribe_resident(wh_ctx* c, const float* pcm, int nb, bool prefetched, const float* next_pcm, int next_nb,
-                               const wh_decode_params* p, int64_t* tokens_out, size_t* n_tokens_out, double t_start) {
+                               const wh_decode_params* p, int64_t* tokens_out, size_t* n_tokens_out, double t_start,
+                               const std::function<int()>& after_enqueue = nullptr) {
     int rc;
     if (!prefetched) {
         c->pre_valid = false;
         rc = run_encoder_pass(c, pcm, nb, c->enc_set);
         if (rc) return rc;
     }
-    std::function<int()> hook;
+    std::function<int()> hook = after_enqueue;   // (host work to run once this batch's encoder and cross-K/V step are enqueued)
     if (next_pcm) {
         hook = [c, next_pcm, next_nb]() -> int {
             // every clip of a device-resident batch is exactly 30 s: fill the per-clip sample / frame counts on the stream
@@ -1194,7 +1197,11 @@ static int transcribe_resident(wh_ctx* c, const float* pcm, int nb, bool prefetc
         };
     }
     rc = run_decode(c, nb, p, tokens_out, p->n_prompt + p->max_new_tokens, n_tokens_out, nullptr, 0, hook);
-    if (rc) return rc;
+    if (rc) {   // the prefetched pass (if the hook got that far) is not adopted: the next call recomputes its encoder states
+        c->pre_valid = false;
+        if (c->s_enc != c->stream) hipStreamSynchronize(c->s_enc);
+        return rc;
+    }
     rc = finish_timing(c, t_start);
     if (c->pre_valid) {          // the resident states are now the prefetched batch's
         c->enc_set ^= 1;
@@ -1287,17 +1294,25 @@ int wh_transcribe_batch_next(wh_ctx* c, const wh_clip* clips, size_t n_clips, co
     CTX_HIP(c, hipMemcpyAsync(c->d_nframes, nf.data(), n_clips * 4, hipMemcpyHostToDevice, s));
     CTX_HIP(c, hipStreamSynchronize(s));
     c->timing.h2d_s = now_s() - t0;   // (a prefetched batch: what was left of its copy)
-    if (next_clips) {   // the next batch's copy goes to the other buffer on the copy stream, beside everything this call enqueues below
+    std::function<int()> copy_next;
+    if (next_clips) {
+        // the next batch's copy goes to the other buffer on the copy stream.  Its (thousands of) copy calls are issued from the hook below,
+        // i.e. after this batch's log-mel, encoder and cross-K/V step have been enqueued: the host-side issue cost (~8 us per clip) then falls
+        // into time the device is busy anyway instead of delaying this batch's first kernel
         std::vector<int> ns2, nf2;
         rc = host_batch_counts(c, next_clips, n_next, ns2, nf2);
         if (rc) return rc;
         float* d_next = buf ? c->pcm : c->pcm2;
-        for (size_t i = 0; i < n_next; i++)
-            CTX_HIP(c, hipMemcpyAsync(d_next + i * WH_CLIP_SAMPLES, next_clips[i].pcm, next_clips[i].n_samples * 4, hipMemcpyHostToDevice, c->s_copy));
-        CTX_HIP(c, hipEventRecord(c->ev_h2d, c->s_copy));
-        c->h2d_buf = buf ^ 1; c->h2d_src = next_clips[0].pcm; c->h2d_n = (int)n_next; c->h2d_ns = ns2; c->h2d_nf = nf2; c->h2d_valid = true;
+        const int nbuf = buf ^ 1;
+        copy_next = [c, next_clips, n_next, d_next, nbuf, ns2, nf2]() -> int {
+            for (size_t i = 0; i < n_next; i++)
+                CTX_HIP(c, hipMemcpyAsync(d_next + i * WH_CLIP_SAMPLES, next_clips[i].pcm, next_clips[i].n_samples * 4, hipMemcpyHostToDevice, c->s_copy));
+            CTX_HIP(c, hipEventRecord(c->ev_h2d, c->s_copy));
+            c->h2d_buf = nbuf; c->h2d_src = next_clips[0].pcm; c->h2d_n = (int)n_next; c->h2d_ns = ns2; c->h2d_nf = nf2; c->h2d_valid = true;
+            return WH_OK;
+        };
     }
-    return transcribe_resident(c, d_pcm, (int)n_clips, false, nullptr, 0, p, tokens_out, n_tokens_out, t0);
+    return transcribe_resident(c, d_pcm, (int)n_clips, false, nullptr, 0, p, tokens_out, n_tokens_out, t0, copy_next);
 }
 
 int wh_transcribe_batch_device_next(wh_ctx* c, const float* d_pcm, size_t n_clips, const float* d_pcm_next, size_t n_clips_next,

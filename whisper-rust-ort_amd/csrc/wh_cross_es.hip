@@ -774,11 +774,11 @@ void wh_launch_layernorm_es2(hipStream_t s, const float* x, const float* w, cons
     hipLaunchKernelGGL(k_layernorm_es2, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, w, b, (_Float16*)y, rows, in_blk, out_blk);
 }
 
-void wh_launch_dec_cross_attn_es(hipStream_t s, int prec, const float* qe, const void* E, void* out, int S, int e_rows, int B, int mpad, bool stream_nt) {
+void wh_launch_dec_cross_attn_es(hipStream_t s, int prec, const float* qe, const void* E, void* out, int S, int e_rows, int B, int mpad, bool stream_nt, int n_cus) {
     static const int nt_env = [] { const char* e = getenv("WH_CROSS_NT"); return e ? atoi(e) : -1; }();
     static const int nl = [] { const char* e = getenv("WH_ES_LOADERS"); return e ? atoi(e) : 1; }();        // (A/B runs) loader waves per workgroup
     static const int persist = [] { const char* e = getenv("WH_ES_PERSIST"); return e ? atoi(e) : 1; }();   // (A/B runs) 0: one workgroup per clip
-    static const int n_cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n; }();
+    if (n_cus <= 0) n_cus = 256;   // (the context passes the population of its decode stream's CU mask, else its device's CU count)
     if (nt_env >= 0) stream_nt = nt_env != 0;
     const int grid = persist ? std::min(B, n_cus) : B;   // one workgroup per CU walks its clips
     if (prec == WH_PREC_F16X3) {   // fp16 limb planes (k_dec_cross_attn_es2)

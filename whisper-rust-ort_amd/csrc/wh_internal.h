@@ -70,6 +70,7 @@ struct wh_model {
 struct wh_ctx {
     wh_model* m = nullptr;
     int max_batch = 1;
+    int dec_cus = 256;              // compute units of the token-loop stream (its CU mask's population, else the device's count)
     hipStream_t stream = nullptr;   // cross-K/V projection + token loop (and everything else when s_enc == stream)
     // log-mel + encoder.  The same stream unless the context was created with wh_ctx_create_ex (CU masks / two streams):
     // then the next batch's encoder runs beside this batch's token loop, each on its own part of the chip.

@@ -199,7 +199,8 @@ bool wh_cross_es_geometry(int d, int n_heads, int S);
 // (head h's rows of W_k, transposed), qe [M][H][d] f32.  q enters the bf16 MFMAs as hi + lo, so nothing of it is rounded.
 // (WH_PREC_F16X3: wkT as h2, E as fp16 limb planes [B][e_rows][hi d | lo d] written by wh_launch_layernorm_es2, out as an h2 slab)
 void wh_launch_dec_qexpand(hipStream_t s, int prec, const float* q, const void* wkT, float* qe, int M, int d, int n_heads);
-void wh_launch_dec_cross_attn_es(hipStream_t s, int prec, const float* qe, const void* E, void* out, int S, int e_rows, int B, int mpad, bool stream_nt);   // e_rows >= S: rows between two clips' states
+// e_rows >= S: rows between two clips' states; n_cus: compute units the launch stream may use (one persistent workgroup per CU)
+void wh_launch_dec_cross_attn_es(hipStream_t s, int prec, const float* qe, const void* E, void* out, int S, int e_rows, int B, int mpad, bool stream_nt, int n_cus);
 void wh_launch_layernorm_es2(hipStream_t s, const float* x, const float* w, const float* b, void* y, long rows, int in_blk, int out_blk);
 
 // dynamic LDS to request for a cross-attention launch of total_wgs workgroups whose kernel needs own_bytes: caps the resident

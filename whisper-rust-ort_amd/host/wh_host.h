@@ -597,7 +597,7 @@ struct PipeItem {
 class BufferPool {
   public:
     BufferPool(std::function<float*()> alloc, std::function<void(float*)> dealloc) : alloc_(std::move(alloc)), free_(std::move(dealloc)) {}
-    ~BufferPool() { for (float* p : free_list_) free_(p); }
+    ~BufferPool() { for (float* p : all_) free_(p); }   // every buffer the pool allocated, wherever an aborted run left it
     // true if the pool holds `n` buffers (allocating them now if this is the first call); false = use pageable memory
     bool ensure(size_t n) {
         std::lock_guard<std::mutex> lk(m_);
@@ -605,12 +605,15 @@ class BufferPool {
         tried_ = true;
         for (size_t i = 0; i < n; i++) {
             float* p = alloc_();
-            if (!p) {   // not enough page-locked memory: give back what was taken, run without the pool
+            if (!p) {   // not enough page-locked memory: give back what was taken, run without the pool — and say so: throughput changes
                 for (float* q : free_list_) free_(q);
                 free_list_.clear();
+                all_.clear();
+                fprintf(stderr, "[wh_host] staging pool: %zu of %zu buffers could be allocated; continuing with pageable memory (slower host-to-device copies)\n", i, n);
                 return false;
             }
             free_list_.push_back(p);
+            all_.push_back(p);
         }
         total_ = n;
         return total_ > 0;
@@ -636,25 +639,29 @@ class BufferPool {
   private:
     std::function<float*()> alloc_;
     std::function<void(float*)> free_;
-    std::vector<float*> free_list_;
+    std::vector<float*> free_list_, all_;
     size_t total_ = 0;
     bool tried_ = false, aborted_ = false;
     std::mutex m_;
     std::condition_variable cv_;
 };
 
-// look-ahead of the loaders / buffers a staging pool needs for it: look-ahead + batches in flight + one per loader
-inline size_t file_pipeline_lookahead(size_t max_batch, size_t n_workers) { return max_batch * n_workers * 2 + 4; }
+// look-ahead of the loaders (files loaded but not yet handed to a worker: one batch per worker — a worker waits for a FULL batch, so
+// anything less would stall it) / buffers a staging pool needs: the look-ahead + the two batches a worker holds (the one it
+// transcribes and the one whose host-to-device copy runs beside it) + one per loader
+inline size_t file_pipeline_lookahead(size_t max_batch, size_t n_workers) { return max_batch * n_workers + 4; }
 inline size_t file_pipeline_pool_size(size_t max_batch, size_t n_workers, int n_loaders) {
-    return file_pipeline_lookahead(max_batch, n_workers) + max_batch * n_workers + (size_t)n_loaders;
+    return file_pipeline_lookahead(max_batch, n_workers) + 2 * max_batch * n_workers + (size_t)n_loaders;
 }
 
-// load(idx, audio, dur) fills one file; process(worker, batch) transcribes a batch of one-window files (<= max_batch of
-// them, only what is already loaded) or ONE multi-window file; both may throw.  Returns the first error ("" = none).
-// `pool` (optional) stages one-window files; its buffers go back to the pool after process() returns.
+// load(idx, audio, dur) fills one file; process(worker, batch, next) transcribes a batch of one-window files (<= max_batch of
+// them, only what is already loaded) or ONE multi-window file; `next` (may be null) is the batch of one-window files this worker
+// will be given next, already loaded — the place to start its host-to-device copy (wh_transcribe_batch_next); both may throw.
+// Returns the first error ("" = none).  `pool` (optional) stages one-window files; a batch's buffers go back to the pool after
+// the process() call that transcribed it returns.
 inline std::string run_file_pipeline(size_t nfiles, int n_loaders, size_t n_workers, size_t max_batch, size_t window_samples, BufferPool* pool,
                                      const std::function<void(size_t, std::vector<float>&, double&)>& load,
-                                     const std::function<void(size_t, std::vector<PipeItem>&)>& process) {
+                                     const std::function<void(size_t, std::vector<PipeItem>&, std::vector<PipeItem>*)>& process) {
     std::mutex mu;
     std::condition_variable cv_items, cv_space;
     std::deque<PipeItem> ready;               // loaded files, in index order
@@ -714,38 +721,61 @@ inline std::string run_file_pipeline(size_t nfiles, int n_loaders, size_t n_work
             cv_items.notify_all();
         }
     };
-    auto worker = [&](size_t wi) {
+    // take the next batch off the queue (under mu): a full batch, the tail of the input, or a multi-window file alone.
+    // `block`: wait for one; else only what is available right now.  Returns false when there is none (end of input, error, or not yet).
+    auto take = [&](std::unique_lock<std::mutex>& lk, bool block, bool one_window_only, std::vector<PipeItem>& batch) -> bool {
+        auto avail = [&] {
+            return !first_error.empty() || handed == nfiles || ready.size() >= max_batch || handed + ready.size() == nfiles ||
+                   (!ready.empty() && ready.front().n() > window_samples);
+        };
         for (;;) {
-            std::vector<PipeItem> batch;
+            if (block) cv_items.wait(lk, avail);
+            else if (!avail()) return false;
+            if (!first_error.empty()) return false;
+            if (ready.empty()) {
+                if (handed == nfiles || !block) return false;
+                continue;
+            }
+            break;
+        }
+        if (ready.front().n() > window_samples) {
+            if (one_window_only) return false;   // a multi-window file is never a "next" batch: it goes alone through the long-form entry
+            batch.push_back(std::move(ready.front()));
+            ready.pop_front();
+        } else {
+            while (!ready.empty() && batch.size() < max_batch && ready.front().n() <= window_samples) {
+                batch.push_back(std::move(ready.front()));
+                ready.pop_front();
+            }
+        }
+        handed += batch.size();
+        return true;
+    };
+    auto give_back = [&](std::vector<PipeItem>& batch) {
+        for (PipeItem& it : batch)
+            if (it.pin) { pool->release(it.pin); it.pin = nullptr; }
+        batch.clear();
+    };
+    auto worker = [&](size_t wi) {
+        std::vector<PipeItem> cur, nxt;
+        bool have_next = false;
+        for (;;) {
             {
                 std::unique_lock<std::mutex> lk(mu);
-                // wait for a full batch, the end of the input, or a multi-window file at the front (it goes alone)
-                cv_items.wait(lk, [&] {
-                    return !first_error.empty() || handed == nfiles || ready.size() >= max_batch || handed + ready.size() == nfiles ||
-                           (!ready.empty() && ready.front().n() > window_samples);
-                });
-                if (!first_error.empty() || ready.empty()) {
-                    if (!first_error.empty() || handed == nfiles) return;
-                    continue;
-                }
-                if (ready.front().n() > window_samples) {
-                    batch.push_back(std::move(ready.front()));
-                    ready.pop_front();
-                } else {
-                    while (!ready.empty() && batch.size() < max_batch && ready.front().n() <= window_samples) {
-                        batch.push_back(std::move(ready.front()));
-                        ready.pop_front();
-                    }
-                }
-                handed += batch.size();
+                if (have_next) { cur = std::move(nxt); nxt.clear(); have_next = false; }
+                else if (!take(lk, true, false, cur)) { give_back(cur); return; }
+                // one batch of look-ahead for this worker, if it is loaded already (never waited for)
+                const bool cur_one_window = cur.size() > 1 || cur[0].n() <= window_samples;
+                if (cur_one_window) have_next = take(lk, false, true, nxt);
             }
             cv_space.notify_all();
             cv_items.notify_all();
             try {
-                process(wi, batch);
-                for (PipeItem& it : batch)
-                    if (it.pin) pool->release(it.pin);
+                process(wi, cur, have_next ? &nxt : nullptr);
+                give_back(cur);
             } catch (const std::exception& e) {
+                give_back(cur);
+                give_back(nxt);
                 fail(e.what());
                 return;
             }

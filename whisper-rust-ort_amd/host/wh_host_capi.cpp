@@ -113,8 +113,20 @@ int whh_pipeline_selftest(size_t nfiles, int n_loaders, size_t n_workers, size_t
         dur = (double)audio.size();
         std::this_thread::sleep_for(std::chrono::microseconds(200 + 37 * (i % 7)));
     };
-    auto process = [&](size_t, std::vector<PipeItem>& batch) {
+    std::atomic<size_t> with_next{0};
+    std::vector<size_t> expect_first(n_workers, (size_t)-1);   // per worker: first index of the batch announced as `next`
+    auto process = [&](size_t wi, std::vector<PipeItem>& batch, std::vector<PipeItem>* next) {
         if (batch.empty() || batch.size() > max_batch) throw std::runtime_error("bad batch size");
+        if (expect_first[wi] != (size_t)-1 && batch[0].idx != expect_first[wi]) throw std::runtime_error("the announced next batch was not the next batch");
+        expect_first[wi] = (size_t)-1;
+        if (next) {
+            if (next->empty() || next->size() > max_batch) throw std::runtime_error("bad next batch size");
+            for (auto& it : *next)
+                if (it.n() > window) throw std::runtime_error("a multi-window file was announced as a next batch");
+            if ((*next)[0].data()[0] != (float)(*next)[0].idx) throw std::runtime_error("next payload mismatch");
+            expect_first[wi] = (*next)[0].idx;
+            with_next++;
+        }
         if (batch.size() > 1)
             for (auto& it : batch)
                 if (it.n() > window) throw std::runtime_error("a multi-window file must go alone");

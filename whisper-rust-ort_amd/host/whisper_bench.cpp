@@ -415,7 +415,7 @@ int main(int argc, char** argv) {
         std::vector<int64_t> prompt = {sp.sot, sp.lang, sp.task};
         if (!a.timestamps) prompt.push_back(sp.no_timestamps);
         std::vector<double> busy_s(ctxs.size(), 0.0);
-        auto process = [&](size_t wi, std::vector<Item>& batch) {
+        auto process = [&](size_t wi, std::vector<Item>& batch, std::vector<Item>* next) {
             wh_ctx* ctx = ctxs[wi];
             const size_t stride = prompt.size() + a.max_new_tokens;
             const double tb0 = now_s();
@@ -432,10 +432,12 @@ int main(int argc, char** argv) {
                 p.prompt = prompt.data(); p.n_prompt = prompt.size(); p.max_new_tokens = a.max_new_tokens; p.eot = sp.eot;
                 p.suppress = gen.suppress.data(); p.n_suppress = gen.suppress.size();
                 p.begin_suppress = gen.begin_suppress.data(); p.n_begin_suppress = gen.begin_suppress.size();
-                std::vector<wh_clip> clips(batch.size());
+                std::vector<wh_clip> clips(batch.size()), nclips(next ? next->size() : 0);
                 for (size_t k = 0; k < batch.size(); k++) { clips[k].pcm = batch[k].data(); clips[k].n_samples = batch[k].n(); }
+                for (size_t k = 0; k < nclips.size(); k++) { nclips[k].pcm = (*next)[k].data(); nclips[k].n_samples = (*next)[k].n(); }
                 const double t0 = now_s();
-                int rc = wh_transcribe_batch(ctx, clips.data(), clips.size(), &p, toks.data(), ntok.data());
+                // the next batch of this worker, if it is loaded already, is copied to the device beside this batch's work
+                int rc = wh_transcribe_batch_next(ctx, clips.data(), clips.size(), nclips.empty() ? nullptr : nclips.data(), nclips.size(), &p, toks.data(), ntok.data());
                 if (rc) throw std::runtime_error(std::string("libwhisper_hip error ") + std::to_string(rc) + ": " + wh_last_error(ctx));
                 const double batch_s = now_s() - t0;
                 wh_timing wt{};
