@@ -852,7 +852,9 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     // 2048-clip launch (tools/es_state_probe.py, WH_ES_PAD = 0 / 12 / 20 / 28 / 44 / 84: 491 / 487 / 482 / 484 / 485 / 490)
     c->es_rows = (int)S + 20;
     if (const char* e = getenv("WH_ES_PAD")) c->es_rows = (int)S + std::max(0, atoi(e));   // (A/B runs)
-    const size_t o_ckv = cv.take(c->cross_es ? B * (size_t)c->es_rows * d * esz : Ld * 2 * B * S * d * esz);
+    c->es_rows_cap = c->es_rows;
+    if (const char* e = getenv("WH_ES_PAD_MAX")) c->es_rows_cap = std::max(c->es_rows, (int)S + atoi(e));   // (probe runs: room for wh_debug_set_es_pad)
+    const size_t o_ckv = cv.take(c->cross_es ? B * (size_t)c->es_rows_cap * d * esz : Ld * 2 * B * S * d * esz);
     const bool f8 = m->prec == WH_PREC_FP8;
     const size_t o_ckv8 = f8 ? cv.take(Ld * 2 * B * S * d) : 0, o_kvam = f8 ? cv.take(Ld * 2 * B * H * 4) : 0;
     // fp8-MFMA encoder (wh_gemm8_mx.hip): MX activations when every contraction length is one the kernel takes
@@ -964,6 +966,15 @@ void wh_ctx_free(wh_ctx* c) {
 }
 
 int wh_ctx_cross_mode(const wh_ctx* c) { return c ? (c->cross_es ? 1 : 0) : -1; }
+
+// probe hook (tools/es_pitch_probe.py; not in the public header): rows of padding between the clips' encoder states, within the room
+// WH_ES_PAD_MAX reserved at creation.  Addresses only — results do not depend on it.
+extern "C" int wh_debug_set_es_pad(wh_ctx* c, int pad_rows) {
+    if (!c || !c->cross_es || pad_rows < 0 || c->m->dims.n_audio_ctx + pad_rows > c->es_rows_cap) return WH_ERR_ARG;
+    c->es_rows = c->m->dims.n_audio_ctx + pad_rows;
+    c->have_enc = false;
+    return WH_OK;
+}
 
 const char* wh_last_error(const wh_ctx* c) { return c ? c->err.c_str() : wh_global_error().c_str(); }
 

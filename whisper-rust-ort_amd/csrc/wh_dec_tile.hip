@@ -143,7 +143,6 @@ __global__ __launch_bounds__(256) void k_dec_tile(SkinnyArgs a) {
         wait_stage(kt);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads of kt - 1 (and, first, its LayerNorm sums) have left LDS
         __builtin_amdgcn_s_barrier();                          // stage kt visible to all; every wave is done with stage kt - 1
-        if (kt + NSLOT - 1 < nk) stage((kt + NSLOT - 1) % NSLOT, kt + NSLOT - 1);
         if (kt == 0 && a.ln_part && tid < BM) {
             const float s1 = lnq[tid * 2] + lnq[(BM + tid) * 2], s2 = lnq[tid * 2 + 1] + lnq[(BM + tid) * 2 + 1];
             float mean, rstd;
@@ -164,6 +163,11 @@ __global__ __launch_bounds__(256) void k_dec_tile(SkinnyArgs a) {
             for (int u = 0; u < 2; u++)
 #pragma unroll
                 for (int j = 0; j < TN; j++) mma16(acc[i0 + u][j], wf[j], af[u]);   // D rows = n (4 fg + e), column = m (fl)
+            if (i0 == 0 && kt + NSLOT - 1 < nk) {   // the LDS-DMA of the stage that reuses the freed slot: behind the first MFMA group (its issue cost
+                __builtin_amdgcn_sched_barrier(0);   // — ~100 cycles per instruction, in order — then falls under the MFMAs' execution)
+                stage((kt + NSLOT - 1) % NSLOT, kt + NSLOT - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     __syncthreads();   // lnstat (written during step 0 by the first 128 threads) visible to everyone

@@ -84,6 +84,16 @@ __global__ __launch_bounds__(512, 2) void k_gemm8x(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; j++) glds16(w_src[j] + (long)kt * ROWB, base + SLOT_A + (wave * 32 + j * 8) * ROWB);
     };
+    auto stage_half = [&](int slot, int kt, int half) {   // half 0: this wave's A rows, half 1: its W rows
+        char* base = smem + slot * SLOT;
+        if (half == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) glds16(a_src[j] + (long)kt * ROWB, base + (wave * 32 + j * 8) * ROWB);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) glds16(w_src[j] + (long)kt * ROWB, base + SLOT_A + (wave * 32 + j * 8) * ROWB);
+        }
+    };
 
     f32x4 acc[TM][TN];   // [m tile][n tile]
 #pragma unroll
@@ -105,7 +115,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm8x(GemmArgs g) {
     for (int kt = 0; kt < nk; kt++) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stage kt has landed
         __builtin_amdgcn_s_barrier();                       // stage kt visible to all; every wave has read the fragments of kt - 1
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
         const char* sb = smem + (kt & 1) * SLOT;
         xfrag wf[TN];
 #pragma unroll
@@ -119,6 +128,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm8x(GemmArgs g) {
             for (int u = 0; u < 2; u++)
 #pragma unroll
                 for (int j = 0; j < TN; j++) mma16(acc[i0 + u][j], wf[j], af[u]);   // D rows = n, cols = m
+            // the next stage's eight LDS-DMA instructions go out behind the first two MFMA groups (24 MFMAs = ~400 cycles of matrix work each):
+            // an LDS-DMA instruction costs its issuer ~100 cycles and a wave issues in order — issued right after the barrier, ahead of the
+            // MFMAs, they held every wave of the workgroup in DMA issue while the matrix pipe idled
+            if (kt + 1 < nk && i0 < 4) {
+                __builtin_amdgcn_sched_barrier(0);
+                stage_half((kt + 1) & 1, kt + 1, i0 >> 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (all fragment reads of this wave have left LDS before the next barrier)
     }
@@ -256,6 +273,16 @@ __global__ __launch_bounds__(512, 2) void k_lm_head_tile_x3(SkinnyArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; j++) glds16(w_src[j] + (long)kt * ROWB, base + SLOT_A + (wave * 32 + j * 8) * ROWB);
     };
+    auto stage_half = [&](int slot, int kt, int half) {
+        char* base = smem + slot * SLOT;
+        if (half == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) glds16(a_src[j] + kt * a_kstep, base + (wave * 32 + j * 8) * ROWB);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) glds16(w_src[j] + (long)kt * ROWB, base + SLOT_A + (wave * 32 + j * 8) * ROWB);
+        }
+    };
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; i++)
@@ -274,7 +301,6 @@ __global__ __launch_bounds__(512, 2) void k_lm_head_tile_x3(SkinnyArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (first step: this wave's quarter sums have left for LDS)
         __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
         if (kt == 0 && a.ln_part && tid < BM) {   // the quarter sums are in LDS since the barrier above
             const float s1 = (lnq[tid * 2] + lnq[(BM + tid) * 2]) + (lnq[(2 * BM + tid) * 2] + lnq[(3 * BM + tid) * 2]);
             const float s2 = (lnq[tid * 2 + 1] + lnq[(BM + tid) * 2 + 1]) + (lnq[(2 * BM + tid) * 2 + 1] + lnq[(3 * BM + tid) * 2 + 1]);
@@ -296,6 +322,11 @@ __global__ __launch_bounds__(512, 2) void k_lm_head_tile_x3(SkinnyArgs a) {
             for (int u = 0; u < 2; u++)
 #pragma unroll
                 for (int j = 0; j < TN; j++) mma16(acc[i0 + u][j], wf[j], af[u]);
+            if (kt + 1 < nk && i0 < 4) {   // the next stage's LDS-DMA behind the first MFMA groups (k_gemm8x's order)
+                __builtin_amdgcn_sched_barrier(0);
+                stage_half((kt + 1) & 1, kt + 1, i0 >> 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     __syncthreads();   // lnstat visible to everyone; the ring is idle

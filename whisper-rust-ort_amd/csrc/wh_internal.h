@@ -150,6 +150,7 @@ struct wh_ctx {
     bool cross_es = false;
     void* es_E = nullptr;
     int es_rows = 0;            // rows from one clip's states to the next in es_E (>= n_audio_ctx)
+    int es_rows_cap = 0;        // rows per clip the buffer was sized for
     float* dq32 = nullptr;      // [B][d] f32 cross-attention queries (pre-scaled)
     float* dqe = nullptr;
     void* dctx = nullptr;
