@@ -721,3 +721,52 @@ def test_cross_es_longform_equals_staged_calls(gpu):
         alone, _ = ctx.greedy_decode_with_past(params)
         assert toks.tolist() == alone.tolist()
     ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm folded around the GEMMs (bf16): rows whose mean is large against their spread, outlier channels
+# ------------------------------------------------------------------------------------------------
+def _offset_model(prec, enc_offset, dec_offset, outlier):
+    """micro-size model whose residual streams carry a common per-row offset and a few outlier channels: the synthetic weights with
+    `enc_offset` / `dec_offset` added to every entry of the encoder / decoder position table and three channels of it scaled by `outlier`."""
+    dims = ms.PRESETS["micro"]
+    sd = ms.synth_state_dict(dims, 11)
+    for name, off in (("model.encoder.embed_positions.weight", enc_offset), ("model.decoder.embed_positions.weight", dec_offset)):
+        t = sd[name].copy()
+        t[:, [5, 77, 200]] *= outlier
+        sd[name] = (t + np.float32(off)).astype(np.float32)
+    return dims, wb.Model.from_weights(dims, ms.flatten_state_dict(dims, sd), 0, prec)
+
+
+@pytest.mark.parametrize("enc_offset,dec_offset,outlier", [(0.0, 0.0, 1.0), (25.0, 0.0, 1.0), (0.0, 0.0, 300.0), (25.0, 25.0, 40.0)])
+def test_folded_layernorm_with_offset_rows_and_outlier_channels(gpu, monkeypatch, enc_offset, dec_offset, outlier):
+    """Round-3 advisor: the folded encoder LayerNorm rounds the RAW residual rows to bf16 and takes the variance as E[x^2] - mean^2; a row whose
+    mean dwarfs its spread (or with outlier channels) could lose what the unfolded LayerNorm kernel keeps.  Encoder states and teacher-forced
+    logits of a bf16 context with the fold against the same context without it (WH_NO_ENC_FOLD=1), both against the exact-f32 mode of the same
+    weights: the fold must stay within 1.5 x the unfolded path's error (+ a small floor)."""
+    pcm = ms.synth_clip(2)
+    forced = np.random.Generator(np.random.PCG64(17)).integers(0, 4099, size=15).tolist()
+    prompt, eot = [3, 5, 7, 9], 2
+    p = wb.DecodeParams(prompt, len(forced) + 1, eot, forced=forced)
+
+    def run(prec, fold):
+        if fold:
+            monkeypatch.delenv("WH_NO_ENC_FOLD", raising=False)
+        else:
+            monkeypatch.setenv("WH_NO_ENC_FOLD", "1")
+        dims, model = _offset_model(prec, enc_offset, dec_offset, outlier)
+        ctx = wb.Context(model, 16)              # above the small-context size: the LDS-DMA GEMMs (and, unless switched off, the fold)
+        enc = ctx.run_encoder(ctx.whisper_log_mel(pcm))
+        _, lg = ctx.greedy_decode_with_past(p, want_logits=True)
+        ctx.close()
+        return enc, lg
+
+    e32, l32 = run(wb.WH_PREC_F32, False)
+    ef, lf = run(wb.WH_PREC_BF16, True)
+    en, ln_ = run(wb.WH_PREC_BF16, False)
+    assert np.isfinite(ef).all() and np.isfinite(lf).all()
+    d_ef, d_en = np.abs(ef - e32).max(), np.abs(en - e32).max()
+    d_lf, d_ln = np.abs(lf - l32).max(), np.abs(ln_ - l32).max()
+    print(f"offset enc {enc_offset} dec {dec_offset} outlier x{outlier}: encoder err fold {d_ef:.4f} / no fold {d_en:.4f}; logit err fold {d_lf:.4f} / no fold {d_ln:.4f}; "
+          f"|enc| max {np.abs(e32).max():.2f}, logit sigma {l32.std():.2f}")
+    assert d_ef <= 1.5 * d_en + 0.02 and d_lf <= 1.5 * d_ln + 0.03

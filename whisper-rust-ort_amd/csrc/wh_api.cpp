@@ -143,12 +143,15 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
     // copy: 3.1 GB less read and one launch less per LayerNorm at 1024 clips.
     const bool fold = c->enc_fold;
     const int n_grp = (int)(d / 64);
-    auto producer = [&](GemmArgs& g) {
+    // `first`: conv2, the first producer of a pass — its rows are shifted by what is known before they exist, the row means of the
+    // positional table it adds (enc_shift0); later producers by the row's true mean at the previous LayerNorm (enc_shift)
+    auto producer = [&](GemmArgs& g, bool first = false) {
         if (!fold) return;
         g.xb_out = c->xb; g.stats_out = c->enc_part; g.stats_rows = rows;
+        g.row_shift = first ? c->enc_shift0 : c->enc_shift;
     };
-    auto finish_stats = [&]() {
-        if (fold) wh_launch_ln_stats(s, c->enc_part, n_grp, rows, (int)d, c->enc_stat);
+    auto finish_stats = [&](bool first = false) {
+        if (fold) wh_launch_ln_stats(s, c->enc_part, n_grp, rows, (int)d, c->enc_stat, c->enc_shift, first ? c->enc_shift0 : c->enc_shift);
     };
     {   // conv2 (k3,s2,p1) + GELU + sinusoid positions → f32 residual stream
         Prof p(c, WH_KG_ENC_GEMM);
@@ -160,9 +163,9 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
         g.bias = m->conv2_b; g.bias_mode = 1; g.act = 1;
         g.R = m->enc_pos; g.ldr = d; g.r_bs = 0;
         g.M = nb * (int)S; g.N = (int)d; g.K = (int)(3 * d);
-        producer(g);
+        producer(g, true);
         CTX_LAUNCH(c, wh_launch_gemm(s, prec, true, g));
-        finish_stats();
+        finish_stats(true);
     }
     for (int l = 0; l < D.enc_layers; l++) {
         const EncLayerDev& L = m->enc[l];
@@ -410,7 +413,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
         if (embed_first) {   // token + position embedding → x, raw slab, row sums (one "tile")
             Prof pr(c, WH_KG_DEC_OTHER);
             wh_launch_dec_embed(s, prec, m->tok_emb, m->dec_pos, c->feed, ld, c->pos, c->dx, c->dxs, c->lnpart, nb, (int)d, mpad,
-                                f8 ? m->dec[0].ln1_w : nullptr);
+                                f8 ? m->dec[0].ln1_w : nullptr, c->dshift);
         }
         for (int l = 0; l < D.dec_layers; l++) {
             const DecLayerDev& L = m->dec[l];
@@ -420,7 +423,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 a = SkinnyArgs();
                 a.X = c->dxs; a.x_mpad = mpad; a.W = L.qkv_w; a.bias = L.qkv_b; a.wscale = L.qkv_sc; a.C = c->dqkv; a.ldc = 3 * d;
                 a.M = nb; a.N = (int)(3 * d); a.K = (int)d;
-                a.ln_part = c->lnpart; a.ln_tiles = (l == 0) ? 1 : ln_tiles_d; a.ln_s = L.qkv_s;
+                a.ln_part = c->lnpart; a.ln_tiles = (l == 0) ? 1 : ln_tiles_d; a.ln_s = L.qkv_s; a.shift_io = c->dshift;
                 dec_gemm(false, a);
             }
             {
@@ -433,7 +436,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 Prof pr(c, WH_KG_DEC_GEMM);
                 a = SkinnyArgs();
                 a.X = c->datt; a.x_mpad = mpad; a.W = L.o_w; a.bias = L.o_b; a.wscale = L.o_sc; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
-                a.M = nb; a.N = (int)d; a.K = (int)d; a.xslab_out = c->dxs; a.stats_out = c->lnpart;
+                a.M = nb; a.N = (int)d; a.K = (int)d; a.xslab_out = c->dxs; a.stats_out = c->lnpart; a.row_shift = c->dshift;
                 if (f8) a.xgamma = L.ln2_w;
                 dec_gemm(true, a);
             }
@@ -443,7 +446,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                     Prof pr(c, WH_KG_DEC_GEMM);
                     a = SkinnyArgs();
                     a.X = c->dxs; a.x_mpad = mpad; a.W = L.cq_w; a.bias = L.cq_b; a.C = c->dq32; a.ldc = d; a.M = nb; a.N = (int)d; a.K = (int)d;
-                    a.ln_part = c->lnpart; a.ln_tiles = ln_tiles_d; a.ln_s = L.cq_s;
+                    a.ln_part = c->lnpart; a.ln_tiles = ln_tiles_d; a.ln_s = L.cq_s; a.shift_io = c->dshift;
                     dec_gemm(true, a);
                     // expanded queries qe[h] = W_k,h^T q_h: [nb][H][d] f32
                     wh_launch_dec_qexpand(s, prec, c->dq32, L.cqx_w, c->dqe, nb, (int)d, D.n_heads);
@@ -466,7 +469,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 Prof pr(c, WH_KG_DEC_GEMM);
                 a = SkinnyArgs();
                 a.X = c->dxs; a.x_mpad = mpad; a.W = L.cq_w; a.bias = L.cq_b; a.wscale = L.cq_sc; a.C = c->dq; a.ldc = d; a.M = nb; a.N = (int)d; a.K = (int)d;
-                a.ln_part = c->lnpart; a.ln_tiles = ln_tiles_d; a.ln_s = L.cq_s;
+                a.ln_part = c->lnpart; a.ln_tiles = ln_tiles_d; a.ln_s = L.cq_s; a.shift_io = c->dshift;
                 dec_gemm(false, a);
             }
             {
@@ -487,7 +490,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 if (c->cross_splits == 1 || c->cross_es) a.X = c->datt;  // one key range per clip: the attention kernel wrote its output itself
                 else { a.xpart = c->cpart; a.xml = c->cml; a.x_splits = c->cross_splits; a.x_heads = D.n_heads; }
                 a.x_mpad = mpad; a.W = L.co_w; a.bias = L.co_b; a.wscale = L.co_sc; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
-                a.M = nb; a.N = (int)d; a.K = (int)d; a.xslab_out = c->dxs; a.stats_out = c->lnpart;
+                a.M = nb; a.N = (int)d; a.K = (int)d; a.xslab_out = c->dxs; a.stats_out = c->lnpart; a.row_shift = c->dshift;
                 if (f8) a.xgamma = L.ln3_w;
                 dec_gemm(true, a);
             }
@@ -496,14 +499,14 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 a = SkinnyArgs();
                 a.X = c->dxs; a.x_mpad = mpad; a.W = L.fc1_w; a.bias = L.fc1_b; a.wscale = L.fc1_sc; a.act = 1; a.C = c->dh; a.c_mpad = mpad;
                 a.M = nb; a.N = (int)F; a.K = (int)d;
-                a.ln_part = c->lnpart; a.ln_tiles = ln_tiles_d; a.ln_s = L.fc1_s;
+                a.ln_part = c->lnpart; a.ln_tiles = ln_tiles_d; a.ln_s = L.fc1_s; a.shift_io = c->dshift;
                 dec_gemm(false, a);
             }
             {   // fc2 + residual → x, raw slab, partials for the next layer's LN1 / the final LN
                 Prof pr(c, WH_KG_DEC_GEMM);
                 a = SkinnyArgs();
                 a.X = c->dh; a.x_mpad = mpad; a.W = L.fc2_w; a.bias = L.fc2_b; a.wscale = L.fc2_sc; a.R = c->dx; a.ldr = d; a.C = c->dx; a.ldc = d;
-                a.M = nb; a.N = (int)d; a.K = (int)F; a.xslab_out = c->dxs; a.stats_out = c->lnpart;
+                a.M = nb; a.N = (int)d; a.K = (int)F; a.xslab_out = c->dxs; a.stats_out = c->lnpart; a.row_shift = c->dshift;
                 if (f8) a.xgamma = (l + 1 < D.dec_layers) ? m->dec[l + 1].ln1_w : m->dec_ln_w;  // next consumer's LayerNorm
                 if (!emits && l == D.dec_layers - 1) { a.ticket = c->step_ticket; a.pos_w = c->pos; }  // prompt position: advance here
                 dec_gemm(true, a);
@@ -525,7 +528,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 Prof pr(c, WH_KG_DEC_OTHER);
                 NextEmbed ne;
                 ne.tok_emb = m->tok_emb; ne.pos_emb = m->dec_pos; ne.x = c->dx; ne.xslab = c->dxs; ne.stats = c->lnpart;
-                ne.xgamma = f8 ? m->dec[0].ln1_w : nullptr; ne.d = (int)d; ne.mpad = mpad;
+                ne.xgamma = f8 ? m->dec[0].ln1_w : nullptr; ne.d = (int)d; ne.mpad = mpad; ne.shift = c->dshift;
                 wh_launch_argmax_finish(s, prec, c->part_val, c->part_idx, lm_parts, mpad, c->pos, c->step_ticket, st, nb, ne);
             }
         }
@@ -873,11 +876,11 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     c->enc_fold = m->prec == WH_PREC_BF16 && max_batch > WH_SMALL_CTX_CLIPS && d >= 256 && (d % 64) == 0 && (F % 64) == 0 && S >= 256 && (S % 4) == 0 &&
                   m->cross_kv_wf != nullptr && wh_gemm8_enabled() && getenv("WH_NO_ENC_FOLD") == nullptr;
     const size_t o_xb = c->enc_fold ? cv.take(B * S * d * 2) : 0, o_epart = c->enc_fold ? cv.take((d / 64) * B * S * 2 * 4) : 0;
-    const size_t o_estat = c->enc_fold ? cv.take(B * S * 2 * 4) : 0;
+    const size_t o_estat = c->enc_fold ? cv.take(B * S * 2 * 4) : 0, o_eshift = c->enc_fold ? cv.take(B * S * 4) : 0, o_eshift0 = c->enc_fold ? cv.take(B * S * 4) : 0;
     const size_t o_sk = cv.take(Ld * B * H * TC * WH_HEAD_DIM * esz), o_sv = cv.take(Ld * B * H * TC * WH_HEAD_DIM * esz);
     const size_t MP = (size_t)c->mpad;  // slab-layout activations: [K/32][MP][32]
     const size_t o_dx = cv.take(B * d * 4), o_dxn = cv.take(MP * d * esz), o_dqkv = cv.take(B * 3 * d * esz);
-    const size_t o_dxs = cv.take(MP * d * esz), o_lnp = cv.take((d / 16) * MP * 2 * 4);
+    const size_t o_dxs = cv.take(MP * d * esz), o_lnp = cv.take((d / 16) * MP * 2 * 4), o_dsh = cv.take(MP * 4);
     const size_t o_datt = cv.take(MP * d * esz), o_dq = cv.take(B * d * esz), o_dh = cv.take(MP * F * esz);
     const size_t o_dqe = c->cross_es ? cv.take(B * H * d * 4) : 0, o_dctx = c->cross_es ? cv.take(MP * H * d * esz) : 0;
     const size_t o_dq32 = c->cross_es ? cv.take(B * d * 4) : 0;
@@ -901,12 +904,24 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     c->cross_kv = w + o_ckv; c->self_k = w + o_sk; c->self_v = w + o_sv;
     if (f8) { c->cross_kv8 = w + o_ckv8; c->kv_amax = (float*)(w + o_kvam); }
     if (c->cross_es) { c->es_E = w + o_ckv; c->cross_kv = nullptr; c->dqe = (float*)(w + o_dqe); c->dctx = w + o_dctx; c->dq32 = (float*)(w + o_dq32); }
-    if (c->enc_fold) { c->xb = w + o_xb; c->enc_part = (float*)(w + o_epart); c->enc_stat = (float*)(w + o_estat); }
+    if (c->enc_fold) { c->xb = w + o_xb; c->enc_part = (float*)(w + o_epart); c->enc_stat = (float*)(w + o_estat); c->enc_shift = (float*)(w + o_eshift); c->enc_shift0 = (float*)(w + o_eshift0); }
+    if (c->enc_fold) {   // the first producer's row offsets: the mean of each position's row of the positional table, for every clip of a batch
+        std::vector<float> pm(S), all(B * S);
+        const float* pos = m->master.data() + m->index.at("model.encoder.embed_positions.weight").first;
+        for (size_t r = 0; r < S; r++) {
+            double acc = 0.0;
+            for (size_t k = 0; k < d; k++) acc += (double)pos[r * d + k];
+            pm[r] = (float)(acc / (double)d);
+        }
+        for (size_t b = 0; b < B; b++) memcpy(all.data() + b * S, pm.data(), S * 4);
+        he = hipMemcpy(c->enc_shift0, all.data(), all.size() * 4, hipMemcpyHostToDevice);
+        if (he != hipSuccess) { hipFree(c->ws); delete c; return wh_fail_hip(he, "hipMemcpy(row offsets)", __FILE__, __LINE__); }
+    }
     if (c->mx_ok) {
         c->xn8 = (unsigned char*)(w + o_xn8); c->xn8_sc = (unsigned char*)(w + o_xn8s);
         c->h8 = (unsigned char*)(w + o_h8); c->h8_sc = (unsigned char*)(w + o_h8s);
     }
-    c->dx = (float*)(w + o_dx); c->dxn = w + o_dxn; c->dxs = w + o_dxs; c->lnpart = (float*)(w + o_lnp); c->dqkv = w + o_dqkv; c->datt = w + o_datt; c->dq = w + o_dq; c->dh = w + o_dh;
+    c->dx = (float*)(w + o_dx); c->dxn = w + o_dxn; c->dxs = w + o_dxs; c->lnpart = (float*)(w + o_lnp); c->dshift = (float*)(w + o_dsh); c->dqkv = w + o_dqkv; c->datt = w + o_datt; c->dq = w + o_dq; c->dh = w + o_dh;
     c->cpart = (float*)(w + o_cpart); c->cml = (float*)(w + o_cml); c->part_val = (float*)(w + o_pv); c->part_idx = (int*)(w + o_pi);
     c->feed = (int*)(w + o_feed); c->out_tokens = (int*)(w + o_out); c->n_out = (int*)(w + o_nout); c->done = (int*)(w + o_done);
     c->forced = (int*)(w + o_forced); c->pos = (int*)(w + o_pos);

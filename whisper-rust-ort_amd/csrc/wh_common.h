@@ -334,6 +334,10 @@ __device__ __forceinline__ float wh_add(float a, float b) {
 #pragma clang fp contract(off)
     return a + b;
 }
+__device__ __forceinline__ float wh_sub(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
 
 #define WH_HIP_CHECK(expr)                                                                      \
     do {                                                                                        \

@@ -149,6 +149,8 @@ __global__ __launch_bounds__(256) void k_dec_tile(SkinnyArgs a) {
             wh_ln_mean_rstd(s1, s2, (float)a.K, false, mean, rstd);
             lnstat[2 * tid] = mean;
             lnstat[2 * tid + 1] = rstd;
+            // the one consumer of a LayerNorm keeps the rows' running offsets up to date (first column tile only)
+            if (a.shift_io && n0 == 0 && blockIdx.z == 0 && m0 + tid < a.M) a.shift_io[m0 + tid] += mean;
         }
         const char* sb = smem + (kt % NSLOT) * SLOT;
         frag_t wf[TN];
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(256) void k_dec_tile(SkinnyArgs a) {
     for (int i = 0; i < TM; i++) {
         const int rloc = wm * 64 + i * 16 + fl, m = mw0 + i * 16 + fl;
         const float mean = a.ln_part ? lnstat[2 * rloc] : 0.0f, rstd = a.ln_part ? lnstat[2 * rloc + 1] : 1.0f;
+        const float sh = (a.row_shift && m < a.M) ? a.row_shift[m] : 0.0f;   // producers: the row's running offset
         f32x4 rr[TN];
 #pragma unroll
         for (int j = 0; j < TN; j++) {
@@ -210,13 +213,13 @@ __global__ __launch_bounds__(256) void k_dec_tile(SkinnyArgs a) {
             if (ok) {
                 if (a.c_mpad) store4((T*)a.C + slab_idx(m, n, a.c_mpad), v[0], v[1], v[2], v[3]);
                 else store4((TO*)a.C + (long)m * a.ldc + n, v[0], v[1], v[2], v[3]);
-                if (a.xslab_out) store4((T*)a.xslab_out + slab_idx(m, n, a.x_mpad), v[0], v[1], v[2], v[3]);
+                if (a.xslab_out) store4((T*)a.xslab_out + slab_idx(m, n, a.x_mpad), v[0] - sh, v[1] - sh, v[2] - sh, v[3] - sh);
             }
-            if (a.stats_out) {   // this 16-column tile's {sum x, sum x^2} of row m: 4 values per lane, then the row's four lane groups
+            if (a.stats_out) {   // this 16-column tile's {sum x, sum x^2} of the centred row m: 4 values per lane, then the row's four lane groups
                 float s1 = 0.0f, s2 = 0.0f;
                 if (ok) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) { s1 += v[e]; s2 = __builtin_fmaf(v[e], v[e], s2); }
+                    for (int e = 0; e < 4; e++) { const float u = v[e] - sh; s1 += u; s2 = __builtin_fmaf(u, u, s2); }
                 }
                 s1 = xrow_sum(s1);
                 s2 = xrow_sum(s2);

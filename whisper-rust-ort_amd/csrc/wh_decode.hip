@@ -70,17 +70,24 @@ __global__ __launch_bounds__(256) void k_dec_embed(const T* __restrict__ tok_emb
                                                    const int* __restrict__ feed, int feed_ld,
                                                    const int* __restrict__ pos_p, float* __restrict__ x,
                                                    T* __restrict__ xslab, float* __restrict__ stats, int rows, int d,
-                                                   int mpad, const float* __restrict__ xgamma) {
+                                                   int mpad, const float* __restrict__ xgamma, float* __restrict__ shift) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63, pos = *pos_p;
     const T* er = tok_emb + (long)feed[row * feed_ld + pos] * d;
     const float* pr = pos_emb + (long)pos * d;
+    // pass 1: the residual row and its mean; pass 2: the slab copy and the sums of the CENTRED row (SkinnyArgs::row_shift)
+    float s0 = 0.0f;
+    for (int c = lane * 4; c < d; c += 256) {
+        const f32x4 v = load4_f32(er + c) + *reinterpret_cast<const f32x4*>(pr + c);
+        *reinterpret_cast<f32x4*>(x + (long)row * d + c) = v;
+        s0 += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    const float mean = shift ? dpp_wave_sum(s0) / (float)d : 0.0f;
     float s1 = 0.0f, s2 = 0.0f;
     for (int c = lane * 4; c < d; c += 256) {
-        f32x4 p = *reinterpret_cast<const f32x4*>(pr + c);
-        f32x4 v = load4_f32(er + c) + p;
-        *reinterpret_cast<f32x4*>(x + (long)row * d + c) = v;
+        f32x4 v = load4_f32(er + c) + *reinterpret_cast<const f32x4*>(pr + c);
+        v -= mean;
         f32x4 g = {1, 1, 1, 1};
         if (xgamma) g = *reinterpret_cast<const f32x4*>(xgamma + c);  // fp8 mode: the first LayerNorm's γ rides on the slab copy
         store4(xslab + slab_idx(row, c, mpad), v[0] * g[0], v[1] * g[1], v[2] * g[2], v[3] * g[3]);
@@ -89,7 +96,11 @@ __global__ __launch_bounds__(256) void k_dec_embed(const T* __restrict__ tok_emb
     }
     s1 = dpp_wave_sum(s1);
     s2 = dpp_wave_sum(s2);
-    if (lane == 0) { stats[2 * row] = s1; stats[2 * row + 1] = s2; }
+    if (lane == 0) {
+        stats[2 * row] = s1;
+        stats[2 * row + 1] = s2;
+        if (shift) shift[row] = mean;
+    }
 }
 
 // ---- decode GEMM: C[m][n] = act(sum_k X[m][k] W[n][k] + bias[n]) (+ R[m][n]),  M <= 64 per row group
@@ -218,6 +229,7 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
         }
     // epilogue operands (wave w finishes row-tile w): fetched now, used last
     f32x4 pre_bias = {0, 0, 0, 0}, pre_r = {0, 0, 0, 0}, pre_ws = {1, 1, 1, 1}, pre_g = {1, 1, 1, 1};
+    float pre_sh = 0.0f;   // the row's running offset (producers: SkinnyArgs::row_shift)
     const int en = n0 + 4 * fg, em = m0 + wave * 16 + fl;
     const bool ep_ok = wave < MT && en < a.N && em < a.M;
     if (ep_ok) {
@@ -225,6 +237,7 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
         if (a.wscale) pre_ws = *reinterpret_cast<const f32x4*>(a.wscale + en);
         if (a.xgamma) pre_g = *reinterpret_cast<const f32x4*>(a.xgamma + en);
         if (a.R) pre_r = *reinterpret_cast<const f32x4*>(a.R + (long)em * a.ldr + en);
+        if (a.row_shift) pre_sh = a.row_shift[em];
     }
     // LayerNorm folded in: reduce the producer's per-tile partial sums of this row group to mean / rstd
     // (while the weight and activation fragments above are in flight)
@@ -340,7 +353,10 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
         // a slab output is another GEMM's operand: the compute type T (== TO wherever both are 2-byte); row-major outputs are TO
         if (a.c_mpad) store4((T*)a.C + slab_idx(em, en, a.c_mpad), v[0], v[1], v[2], v[3]);
         else store4((TO*)a.C + (long)em * a.ldc + en, v[0], v[1], v[2], v[3]);
-        if (a.xslab_out) store4((T*)a.xslab_out + slab_idx(em, en, a.x_mpad), v[0] * pre_g[0], v[1] * pre_g[1], v[2] * pre_g[2], v[3] * pre_g[3]);
+        if (a.xslab_out) store4((T*)a.xslab_out + slab_idx(em, en, a.x_mpad), wh_sub(v[0], pre_sh) * pre_g[0], wh_sub(v[1], pre_sh) * pre_g[1],
+                                wh_sub(v[2], pre_sh) * pre_g[2], wh_sub(v[3], pre_sh) * pre_g[3]);
+        // the one consumer of a LayerNorm keeps the rows' running offsets up to date (first column tile only)
+        if (a.shift_io && blockIdx.x == 0 && blockIdx.z == 0 && fg == 0) a.shift_io[em] += ln_mean;
     }
     if (a.stats_out && wave < MT) {
         // this column tile's {sum x, sum x^2} per row: 4 values per lane, then the 4 lane groups of the row
@@ -354,7 +370,7 @@ __global__ __launch_bounds__(NW * 64) void k_dec_gemm(SkinnyArgs a) {
             }
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const float v = wh_add(wh_add(wh_scale(s[e], pre_ws[e]), pre_bias[e]), pre_r[e]);  // producers have no activation
+                const float v = wh_sub(wh_add(wh_add(wh_scale(s[e], pre_ws[e]), pre_bias[e]), pre_r[e]), pre_sh);  // producers have no activation
                 s1 += v;
                 s2 = __builtin_fmaf(v, v, s2);   // explicit: the same bits in k_dec_gemm and k_dec_gemm_wide
             }
@@ -408,6 +424,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_dec_gemm_wide(SkinnyArgs a) {
     int en[TPW], em[TPW];
     bool ep_ok[TPW];
     f32x4 pre_r[TPW];
+    float pre_sh[TPW];   // the rows' running offsets (producers: SkinnyArgs::row_shift)
 #pragma unroll
     for (int j = 0; j < TPW; j++) {
         const int t = wave + j * NW;
@@ -415,7 +432,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_dec_gemm_wide(SkinnyArgs a) {
         em[j] = m0 + (t % MT) * 16 + fl;
         ep_ok[j] = t < TILES && en[j] < a.N && em[j] < a.M;
         pre_r[j] = f32x4{0, 0, 0, 0};
+        pre_sh[j] = 0.0f;
         if (ep_ok[j] && a.R) pre_r[j] = *reinterpret_cast<const f32x4*>(a.R + (long)em[j] * a.ldr + en[j]);
+        if (ep_ok[j] && a.row_shift) pre_sh[j] = a.row_shift[em[j]];
     }
     float* lnred = reinterpret_cast<float*>(smem_raw) + (size_t)NW * TILES * 64 * 4;  // [4][MT*16][2]
     if (a.ln_part) {
@@ -513,7 +532,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_dec_gemm_wide(SkinnyArgs a) {
             }
             if (a.c_mpad) store4((T*)a.C + slab_idx(em[j], en[j], a.c_mpad), v[0], v[1], v[2], v[3]);
             else store4((TO*)a.C + (long)em[j] * a.ldc + en[j], v[0], v[1], v[2], v[3]);
-            if (a.xslab_out) store4((T*)a.xslab_out + slab_idx(em[j], en[j], a.x_mpad), v[0] * pre_g[j][0], v[1] * pre_g[j][1], v[2] * pre_g[j][2], v[3] * pre_g[j][3]);
+            if (a.xslab_out) store4((T*)a.xslab_out + slab_idx(em[j], en[j], a.x_mpad), wh_sub(v[0], pre_sh[j]) * pre_g[j][0], wh_sub(v[1], pre_sh[j]) * pre_g[j][1],
+                                    wh_sub(v[2], pre_sh[j]) * pre_g[j][2], wh_sub(v[3], pre_sh[j]) * pre_g[j][3]);
+            if (a.shift_io && blockIdx.x == 0 && blockIdx.z == 0 && t / MT == 0 && fg == 0) a.shift_io[em[j]] += ln_mean;   // (first column tile only)
         }
         if (a.stats_out) {
             // this column tile's {sum x, sum x^2} per row (producers have no activation: v = s*ws + bias + r, as in k_dec_gemm)
@@ -521,7 +542,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_dec_gemm_wide(SkinnyArgs a) {
             if (ep_ok[j]) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const float u = wh_add(wh_add(wh_scale(s[e], pre_ws[j][e]), pre_bias[j][e]), pre_r[j][e]);
+                    const float u = wh_sub(wh_add(wh_add(wh_scale(s[e], pre_ws[j][e]), pre_bias[j][e]), pre_r[j][e]), pre_sh[j]);
                     s1 += u;
                     s2 = __builtin_fmaf(u, u, s2);
                 }
@@ -773,11 +794,25 @@ __global__ __launch_bounds__(256) void k_argmax_finish(const float* __restrict__
         __syncthreads();
         const T* er = (const T*)ne.tok_emb + (long)next * ne.d;
         const float* pr = ne.pos_emb + (long)(pos + 1) * ne.d;
+        // the row's mean first (k_dec_embed's two passes): the slab copy and the sums are of the centred row
+        float mean = 0.0f;
+        if (ne.shift) {
+            float s0 = 0.0f;
+            for (int c = tid * 4; c < ne.d; c += 1024) {
+                const f32x4 v = load4_f32(er + c) + *reinterpret_cast<const f32x4*>(pr + c);
+                s0 += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+            s0 = dpp_wave_sum(s0);
+            if ((tid & 63) == 0) sv[8 + (tid >> 6)] = s0;
+            __syncthreads();
+            mean = ((sv[8] + sv[9]) + (sv[10] + sv[11])) / (float)ne.d;
+        }
         float s1 = 0.0f, s2 = 0.0f;
         for (int c = tid * 4; c < ne.d; c += 1024) {
             const f32x4 p4 = *reinterpret_cast<const f32x4*>(pr + c);
-            const f32x4 v = load4_f32(er + c) + p4;
+            f32x4 v = load4_f32(er + c) + p4;
             *reinterpret_cast<f32x4*>(ne.x + (long)b * ne.d + c) = v;
+            v -= mean;
             f32x4 g = {1, 1, 1, 1};
             if (ne.xgamma) g = *reinterpret_cast<const f32x4*>(ne.xgamma + c);
             store4((T*)ne.xslab + slab_idx(b, c, ne.mpad), v[0] * g[0], v[1] * g[1], v[2] * g[2], v[3] * g[3]);
@@ -791,6 +826,7 @@ __global__ __launch_bounds__(256) void k_argmax_finish(const float* __restrict__
         if (tid == 0) {
             ne.stats[2 * b] = (sv[0] + sv[1]) + (sv[2] + sv[3]);
             ne.stats[2 * b + 1] = (sv[4] + sv[5]) + (sv[6] + sv[7]);
+            if (ne.shift) ne.shift[b] = mean;
         }
     }
     advance_if_last(ticket, pos_p, gridDim.x);
@@ -1319,14 +1355,14 @@ void wh_launch_dec_gemm(hipStream_t s, int prec, bool out_f32, const SkinnyArgs&
 }
 
 void wh_launch_dec_embed(hipStream_t s, int prec, const void* tok_emb, const float* pos_emb, const int* feed, int feed_ld,
-                         const int* pos_p, float* x, void* xslab, float* stats, int rows, int d, int mpad, const float* xgamma) {
+                         const int* pos_p, float* x, void* xslab, float* stats, int rows, int d, int mpad, const float* xgamma, float* shift) {
     dim3 grid((rows + 3) / 4);
     if (prec == WH_PREC_F16X3)
-        hipLaunchKernelGGL(k_dec_embed<h2>, grid, dim3(256), 0, s, (const h2*)tok_emb, pos_emb, feed, feed_ld, pos_p, x, (h2*)xslab, stats, rows, d, mpad, xgamma);
+        hipLaunchKernelGGL(k_dec_embed<h2>, grid, dim3(256), 0, s, (const h2*)tok_emb, pos_emb, feed, feed_ld, pos_p, x, (h2*)xslab, stats, rows, d, mpad, xgamma, shift);
     else if (prec == WH_PREC_F32)
-        hipLaunchKernelGGL(k_dec_embed<float>, grid, dim3(256), 0, s, (const float*)tok_emb, pos_emb, feed, feed_ld, pos_p, x, (float*)xslab, stats, rows, d, mpad, xgamma);
+        hipLaunchKernelGGL(k_dec_embed<float>, grid, dim3(256), 0, s, (const float*)tok_emb, pos_emb, feed, feed_ld, pos_p, x, (float*)xslab, stats, rows, d, mpad, xgamma, shift);
     else
-        hipLaunchKernelGGL(k_dec_embed<bf16>, grid, dim3(256), 0, s, (const bf16*)tok_emb, pos_emb, feed, feed_ld, pos_p, x, (bf16*)xslab, stats, rows, d, mpad, xgamma);
+        hipLaunchKernelGGL(k_dec_embed<bf16>, grid, dim3(256), 0, s, (const bf16*)tok_emb, pos_emb, feed, feed_ld, pos_p, x, (bf16*)xslab, stats, rows, d, mpad, xgamma, shift);
 }
 
 template <typename T>

@@ -354,7 +354,13 @@ __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs
                 else store4(cp, v0[0], v0[1], v0[2], v0[3]);          // N % 8 == 4: the last group holds 4 valid columns
                 if constexpr (sizeof(TO) == 4) {
                     // producer of a LayerNorm input (N % 64 == 0 and contiguous rows checked at launch): the row segment again as
-                    // bf16 — the consumer GEMMs' operand — and its contribution to the row's {sum, sum of squares}
+                    // bf16 — the consumer GEMMs' operand — and its contribution to the row's {sum, sum of squares}; both of the row
+                    // minus its running offset (GemmArgs::row_shift)
+                    if (g.row_shift) {
+                        const float sh = g.row_shift[m];
+                        v0 -= sh;
+                        v1 -= sh;
+                    }
                     if (g.xb_out) store8((bf16*)g.xb_out + z * g.c_zs + mb * g.c_bs + mi * g.ldc + nc0 + c8, v0, v1);
                     if (g.stats_out) {
 #pragma unroll
@@ -611,7 +617,8 @@ bool wh_gemm8_applicable(const GemmArgs& g) {
 }
 
 // {mean, rstd} per row from the producers' per-(64-column group, row) partial sums; groups are added in order (deterministic)
-__global__ __launch_bounds__(256) void k_ln_stats(const float* __restrict__ partials, int groups, long rows, float inv_d, float* __restrict__ stat) {
+__global__ __launch_bounds__(256) void k_ln_stats(const float* __restrict__ partials, int groups, long rows, float inv_d, float* __restrict__ stat,
+                                                  float* __restrict__ shift, const float* __restrict__ shift_in) {
     typedef __attribute__((ext_vector_type(2))) float f32x2;
     const long r = (long)blockIdx.x * 256 + threadIdx.x;
     if (r >= rows) return;
@@ -627,6 +634,7 @@ __global__ __launch_bounds__(256) void k_ln_stats(const float* __restrict__ part
     float mean, rstd;
     wh_ln_mean_rstd(s1, s2, inv_d, true, mean, rstd);
     *reinterpret_cast<f32x2*>(stat + 2 * r) = f32x2{mean, rstd};
+    if (shift) shift[r] = (shift_in ? shift_in[r] : 0.0f) + mean;   // offset the producer used + the mean measured on its shifted rows = the row's true mean
 }
 
 // LM head at hundreds of rows (bf16 operands): argmax partials per row = column tiles x 4 (layout [part][x_mpad])
@@ -644,8 +652,8 @@ void wh_launch_lm_head_tile(hipStream_t s, const SkinnyArgs& a) {
     hipLaunchKernelGGL(k_lm_head_tile, grid, dim3(512), sm, s, a);
 }
 
-void wh_launch_ln_stats(hipStream_t s, const float* partials, int groups, long rows, int d, float* stat) {
-    hipLaunchKernelGGL(k_ln_stats, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, partials, groups, rows, 1.0f / (float)d, stat);
+void wh_launch_ln_stats(hipStream_t s, const float* partials, int groups, long rows, int d, float* stat, float* shift, const float* shift_in) {
+    hipLaunchKernelGGL(k_ln_stats, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, partials, groups, rows, 1.0f / (float)d, stat, shift, shift_in);
 }
 
 int wh_launch_gemm8(hipStream_t s, bool out_f32, const GemmArgs& g) {

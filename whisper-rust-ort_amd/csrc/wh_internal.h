@@ -142,6 +142,8 @@ struct wh_ctx {
     void* xb = nullptr;            // [B][S][d] bf16
     float* enc_part = nullptr;     // [d/64][B*S][2]
     float* enc_stat = nullptr;     // [B*S][2]
+    float* enc_shift = nullptr;    // [B*S] running row offsets of the folded LayerNorms (GemmArgs::row_shift)
+    float* enc_shift0 = nullptr;   // [B*S] the first producer's offsets: the row means of the positional table (conv2 adds it), fixed
     int ldv = 0;
     void* cross_kv = nullptr;   // [Ld][2][B][S][d]
     // cross-attention on the encoder states (wh_cross_es.hip): decided at creation from the model and the context's capacity.
@@ -162,6 +164,7 @@ struct wh_ctx {
     void* dxn = nullptr;        // [B][d]
     void* dxs = nullptr;        // raw residual rows, compute dtype, slab layout [d/32][mpad][32]
     float* lnpart = nullptr;    // LayerNorm partial sums [d/16][mpad][2]
+    float* dshift = nullptr;    // [mpad] running row offsets of the decoder's folded LayerNorms (SkinnyArgs::row_shift / shift_io)
     void* dqkv = nullptr;       // [B][3d]
     void* datt = nullptr;       // [B][d]
     void* dq = nullptr;         // [B][d]

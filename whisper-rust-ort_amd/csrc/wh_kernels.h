@@ -50,6 +50,12 @@ struct GemmArgs {
     void* xb_out = nullptr;
     float* stats_out = nullptr;
     long stats_rows = 0;
+    //            Row centring (round 4): xb_out and the partial sums are taken of v - row_shift[m] — the row's running offset, kept by
+    //            k_ln_stats as (previous offset + the mean measured on the shifted rows), i.e. the previous LayerNorm's true row mean.  A
+    //            LayerNorm is invariant under a per-row shift of its input (the consumers' formula holds with the shifted rows' own mean),
+    //            but the bf16 rounding of the raw rows and the E[x^2] - mean^2 variance are not: with |mean| >> spread they lose the
+    //            row's content (measured: encoder error 0.97 against 0.07 at mean 25, spread 1).  nullptr: no shift (the first producer).
+    const float* row_shift = nullptr;
 };
 
 struct SkinnyArgs {
@@ -82,6 +88,12 @@ struct SkinnyArgs {
     // raw rows in the compute dtype, slab layout, and this column tile's partial sums
     void* xslab_out = nullptr;   // [N/32][x_mpad][32]
     float* stats_out = nullptr;  // [N/16][x_mpad][2]
+    // Row centring of the folded LayerNorms (see GemmArgs::row_shift): producers write the slab copy and the partial sums of
+    // v - row_shift[m]; the one consumer of a LayerNorm adds the mean it measured to shift_io[m] (its first column tile's workgroups
+    // only), so the next producer subtracts the row's true mean of one LayerNorm earlier.  The embedding kernels start a position with
+    // the exact row mean.  Both [x_mpad] f32, the same array.
+    const float* row_shift = nullptr;
+    float* shift_io = nullptr;
     // grouped form (gridDim.z = zn independent products sharing M, N, K): group z reads X + z * x_zs and W + z * w_zs (elements),
     // bias + z * bias_zs, and writes C + z * c_zs (elements).  The per-head V projection of the encoder-state cross-attention:
     // X = head z's 512 context values (16 k-slabs), W = rows 64 z .. of W_v, C = columns 64 z .. of the attention output slab.
@@ -110,6 +122,7 @@ struct NextEmbed {
     float* x = nullptr;              // [B][d] f32 residual stream
     void* xslab = nullptr;           // slab copy (compute dtype), scaled by xgamma when given
     float* stats = nullptr;          // [mpad][2] {sum x, sum x^2}
+    float* shift = nullptr;          // [mpad]: the row's mean, subtracted from the slab copy and the sums (SkinnyArgs::row_shift)
     const float* xgamma = nullptr;
     int d = 0, mpad = 0;
 };
@@ -144,7 +157,9 @@ bool wh_gemm8_enabled();   // false under WH_GEMM8=0 (A/B switch): every GEMM on
 // wh_gemm8.hip: the 8-wave LDS-DMA kernel (bf16 operands) for problems with at least one full 256 x 128 tile
 bool wh_gemm8_applicable(const GemmArgs& g);
 // {mean, rstd} per row from the producers' partial sums: stat[row][2] <- partials[groups][rows][2] (groups added in order)
-void wh_launch_ln_stats(hipStream_t s, const float* partials, int groups, long rows, int d, float* stat);
+// shift (optional, [rows]): the rows' running offsets — shift[r] = shift_in[r] (the offset the producer subtracted; nullptr: none) + mean[r];
+// shift_in == shift updates them in place
+void wh_launch_ln_stats(hipStream_t s, const float* partials, int groups, long rows, int d, float* stat, float* shift = nullptr, const float* shift_in = nullptr);
 int wh_launch_gemm8(hipStream_t s, bool out_f32, const GemmArgs& g);
 // wh_gemm8x.hip: WH_PREC_F16X3 on 256 x 256 LDS-DMA tiles, h2 operands, f32 or h2 results
 bool wh_gemm8x_applicable(const GemmArgs& g, bool out_h2);
@@ -172,7 +187,7 @@ void wh_launch_dec_gemm(hipStream_t s, int prec, bool out_f32, const SkinnyArgs&
 bool wh_dec_tile_applicable(int prec, const SkinnyArgs& a);
 void wh_launch_dec_tile(hipStream_t s, int prec, bool out_f32, const SkinnyArgs& a);
 void wh_launch_dec_embed(hipStream_t s, int prec, const void* tok_emb, const float* pos_emb, const int* feed, int feed_ld,
-                         const int* pos_p, float* x, void* xslab, float* stats, int rows, int d, int mpad, const float* xgamma);
+                         const int* pos_p, float* x, void* xslab, float* stats, int rows, int d, int mpad, const float* xgamma, float* shift);
 void wh_launch_lm_head(hipStream_t s, int prec, const SkinnyArgs& a);
 // wh_gemm8.hip: the same contract on 256 x 256 LDS-DMA tiles for hundreds of rows (bit-identical logits; bf16 operands)
 bool wh_lm_head_tile_applicable(const SkinnyArgs& a);
