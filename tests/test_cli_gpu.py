@@ -23,7 +23,8 @@ def _write_wav(path, pcm):
     return x.astype(np.float32) / np.float32(32768)
 
 
-def test_cli_end_to_end_matches_oracle_tokens(tmp_path):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_cli_end_to_end_matches_oracle_tokens(tmp_path, precision):
     if wb.device_count() < 1:
         pytest.fail("no MI355X visible")
     adir = tmp_path / "audio"
@@ -57,7 +58,7 @@ def test_cli_end_to_end_matches_oracle_tokens(tmp_path):
     clips = {"b_short.wav": ms.synth_clip(71)[:100000], "a_long.wav": np.concatenate([ms.synth_clip(72), ms.synth_clip(73)[:250000]])}
     pcm = {k: _write_wav(str(adir / k), v) for k, v in clips.items()}
     out = tmp_path / "res"
-    r = subprocess.run([CLI, "--audio-dir", str(adir), "--onnx-dir", str(mdir), "--max-new-tokens", "6", "--precision", "f32",
+    r = subprocess.run([CLI, "--audio-dir", str(adir), "--onnx-dir", str(mdir), "--max-new-tokens", "6", "--precision", precision,
                         "--out-csv", str(out / "p.csv"), "--out-json", str(out / "p.json"), "--out-summary-json", str(out / "s.json"),
                         "--write-txt", "--warmup", "1", "--intra-op", "1"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
