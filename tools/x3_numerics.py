@@ -72,7 +72,23 @@ def conv1d(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
     return y if b is None else y + b[None, :, None]
 
 
+VARIANT = ""   # --variant: operands carried as ONE fp16 limb in chosen places (what would it cost in accuracy?)
+
+
 def matmul(a, b):
+    # HF eager attention: scores = matmul(q, k^T) with k^T [.., 64, keys]; output = matmul(P, V) with P [.., queries, keys], V [.., keys, 64]
+    is_scores = b.shape[-2] == 64 and a.shape[-1] == 64
+    keys = b.shape[-1] if is_scores else b.shape[-2]
+    enc_self = keys == 1500 and a.shape[-2] == 1500
+    dec_self = keys <= 448
+    ah, al, _ = split(a)
+    bh, bl, _ = split(b)
+    if VARIANT == "enc_p_single" and enc_self and not is_scores:          # encoder P . V with P as one limb
+        return _matmul(ah, bh) + _matmul(ah, bl)
+    if VARIANT == "dec_self_kv_single" and dec_self:                      # decoder self-attention with the cached K and V as one limb
+        return _matmul(ah, bh) + _matmul(al, bh)
+    if VARIANT == "enc_p_and_dec_kv" and ((enc_self and not is_scores) or dec_self):
+        return (_matmul(ah, bh) + _matmul(ah, bl)) if (enc_self and not is_scores) else (_matmul(ah, bh) + _matmul(al, bh))
     return mm3(a, b, _matmul)
 
 
@@ -84,7 +100,7 @@ def run(model, mel, prompt, forced, eot):
 
 
 def main():
-    global TERMS, ROUND_ONLY, LIMB, SCALE_A, SCALE_B
+    global TERMS, ROUND_ONLY, LIMB, SCALE_A, SCALE_B, VARIANT
     ap = argparse.ArgumentParser()
     ap.add_argument("--preset", default="base")
     ap.add_argument("--seed", type=int, default=1234)
@@ -93,12 +109,14 @@ def main():
     ap.add_argument("--terms", type=int, default=3)
     ap.add_argument("--round-only", action="store_true")
     ap.add_argument("--limb", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--variant", default="", choices=["", "enc_p_single", "dec_self_kv_single", "enc_p_and_dec_kv"])
     ap.add_argument("--scale-a", type=int, default=0)
     ap.add_argument("--scale-b", type=int, default=0)
     a = ap.parse_args()
     TERMS, ROUND_ONLY = a.terms, a.round_only
     LIMB = torch.float16 if a.limb == "f16" else torch.bfloat16
     SCALE_A, SCALE_B = 2.0 ** a.scale_a, 2.0 ** a.scale_b
+    VARIANT = a.variant
     torch.set_num_threads(8)
     dims = ms.PRESETS[a.preset]
     sd = ms.synth_state_dict(dims, a.seed)
@@ -123,7 +141,7 @@ def main():
         F.linear, F.conv1d, torch.matmul = _linear, _conv1d, _matmul
     d = np.abs(rows1 - rows0)
     top = np.sort(rows0, axis=1)[:, -2:]
-    print(f"preset {a.preset} limb {a.limb} scale 2^{a.scale_a},2^{a.scale_b} terms {TERMS} round_only {ROUND_ONLY}: encoder max |d| {np.abs(enc1 - enc0).max():.3e} (|enc| max {np.abs(enc0).max():.2f}); "
+    print(f"preset {a.preset} variant {a.variant!r} limb {a.limb} scale 2^{a.scale_a},2^{a.scale_b} terms {TERMS} round_only {ROUND_ONLY}: encoder max |d| {np.abs(enc1 - enc0).max():.3e} (|enc| max {np.abs(enc0).max():.2f}); "
           f"logits max |d| {d.max():.3e} mean {d.mean():.3e}; logit sigma {rows0.std():.2f}; min top-1 margin {np.min(top[:, 1] - top[:, 0]):.3e}; "
           f"argmax equal {int((rows1.argmax(1) == rows0.argmax(1)).sum())}/{len(rows0)}")
 
