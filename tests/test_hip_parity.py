@@ -335,6 +335,46 @@ def test_gemm8_off_switch_keeps_the_result_or_fails_loudly(gpu, golden_dir, monk
     ctx.close()
 
 
+def test_one_launch_feed_forward_block_against_the_two_gemm_form(gpu, golden_dir, monkeypatch):
+    """k_enc_mlp (wh_mlp.hip: a layer's fc1 + GELU + fc2 + residual in one launch, hidden activations in LDS) against the two k_gemm8 launches it
+    replaces (WH_ENC_MLP=0 at context creation): the same roundings in the same places (h to bf16, f32 residual stream), so the encoder output
+    differs by accumulation order only — held far inside the bf16 bound — and both forms meet the golden logit bound.  A one-clip call on the
+    32-clip context exercises the tile that is cut by the end of the rows (1500 = 11 x 128 + 92)."""
+    g = np.load(os.path.join(golden_dir, "base_s1234_c0.npz"))
+    prompt, eot = g["prompt"].tolist(), int(g["eot"])
+    forced = g["forced_c"].tolist()
+    model = wb.Model("synthetic:base:1234", 0, wb.WH_PREC_BF16)
+    clips = [ms.synth_clip(0)] + [ms.synth_clip(310 + i) for i in range(31)]
+    enc, lgs, toks = {}, {}, {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("WH_ENC_MLP", form)
+        ctx = wb.Context(model, 32)
+        enc[form] = ctx.run_encoder(ctx.whisper_log_mel(clips[0]))
+        toks[form] = [t.tolist() for t in ctx.transcribe_batch(clips, wb.DecodeParams(prompt, 8, eot, [eot]))]
+        _, lg = ctx.greedy_decode_resident_rows(wb.DecodeParams(prompt, len(forced) + 1, eot, forced=forced), [0])
+        lgs[form] = lg[0]
+        ctx.close()
+    d_enc = float(np.abs(enc["1"] - enc["0"]).max())
+    err = {f: max(float(np.abs(lgs[f][i][g["top_ids_c"][i]] - g["top_vals_c"][i]).max()) for i in range(len(forced) + 1)) for f in lgs}
+    same = sum(a == b for a, b in zip(toks["1"], toks["0"]))
+    print(f"one-launch feed-forward block vs two GEMMs, bf16 base, 32-clip context: max |encoder out diff| {d_enc:.2e} (encoder outputs up to "
+          f"{float(np.abs(enc['0']).max()):.1f}); max |logit - golden| {err['1']:.4f} vs {err['0']:.4f}; {same} / 32 clips with identical 8-token decodes")
+    assert np.isfinite(enc["1"]).all() and d_enc < 0.25 * BF16_ENC_BOUND
+    assert err["1"] < BF16_LOGIT_BOUND and err["0"] < BF16_LOGIT_BOUND
+
+
+def test_feed_forward_kernel_matches_host_restatement(gpu):
+    """tools/mlp_check: k_enc_mlp alone against a double-precision host restatement (fold, erf GELU, h rounded to bf16, second product, bias,
+    residual; the bf16 copy and the LayerNorm partial sums of the new rows) at 128 / 300 / 1500 / 13500 rows — whole tiles, a cut tile, one
+    clip, nine clips."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "mlp_check")
+    assert os.path.exists(exe), f"{exe} missing: __graft_entry__.build() compiles it"
+    r = subprocess.run([exe, "16"], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0 and "MISMATCH" not in r.stdout, r.stdout + r.stderr
+
+
 def test_bf16_batch_is_deterministic_and_permutation_invariant(gpu):
     b = bundle("micro", 11, wb.WH_PREC_BF16, max_batch=16)
     prompt, eot = small_prompt(b.dims)

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libwhisper_hip.so")
-SOURCES = ["wh_mel.hip", "wh_gemm.hip", "wh_gemm8.hip", "wh_gemm8x.hip", "wh_gemm8_mx.hip", "wh_attn.hip", "wh_decode.hip", "wh_dec_tile.hip", "wh_cross_es.hip", "wh_fp8.hip", "wh_model.cpp", "wh_api.cpp"]
+SOURCES = ["wh_mel.hip", "wh_gemm.hip", "wh_gemm8.hip", "wh_gemm8x.hip", "wh_gemm8_mx.hip", "wh_mlp.hip", "wh_attn.hip", "wh_decode.hip", "wh_dec_tile.hip", "wh_cross_es.hip", "wh_fp8.hip", "wh_model.cpp", "wh_api.cpp"]
 HEADERS = ["wh_common.h", "wh_kernels.h", "wh_internal.h", "wh_json.h", "../../include/whisper_hip.h"]
 # -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx950's register file is unified).  With the default
 # heuristic the attention kernel kept its score and output tiles in AGPRs and spent 160 of ~400 VALU instructions
@@ -63,12 +63,12 @@ TOOLS = os.path.join(HERE, "..", "tools")
 
 
 def build_tools(verbose: bool = False, force: bool = False) -> None:
-    """Device-side check binaries the GPU tests run (tests/test_fp8_gpu.py): the MX MFMA layout probe and the MX GEMM /
-    LayerNorm kernels against a host restatement.  They include the library's kernel source directly."""
+    """Device-side check binaries the GPU tests run (tests/test_fp8_gpu.py, tests/test_hip_parity.py): the MX MFMA layout probe, the MX GEMM /
+    LayerNorm kernels and the one-launch feed-forward block (k_enc_mlp) against host restatements.  They include the library's kernel source directly."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    for name in ("mx_mfma_check", "mx_gemm_check"):
+    for name, kernel_src in (("mx_mfma_check", "wh_gemm8_mx.hip"), ("mx_gemm_check", "wh_gemm8_mx.hip"), ("mlp_check", "wh_mlp.hip")):
         src, exe = os.path.join(TOOLS, name + ".hip"), os.path.join(TOOLS, name)
-        deps = [src, os.path.join(CSRC, "wh_gemm8_mx.hip"), os.path.join(CSRC, "wh_common.h"), os.path.join(CSRC, "wh_kernels.h")]
+        deps = [src, os.path.join(CSRC, kernel_src), os.path.join(CSRC, "wh_common.h"), os.path.join(CSRC, "wh_kernels.h")]
         if force or _stale(exe, deps):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-w", "-I", CSRC, src, "-o", exe]
             if verbose:

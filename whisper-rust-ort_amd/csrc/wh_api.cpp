@@ -221,6 +221,16 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
             if (mx) CTX_LAUNCH(c, wh_launch_layernorm_mx(s, c->x, L.ln2_w, L.ln2_b, c->xn8, c->xn8_sc, rows, (int)d));
             else wh_launch_layernorm(s, prec, c->x, L.ln2_w, L.ln2_b, c->xn, rows, (int)d);
         }
+        if (c->enc_mlp) {   // the feed-forward block in one launch (wh_mlp.hip; decided with the context — the two-launch form's hidden-activation buffer does not exist then)
+            Prof p(c, WH_KG_ENC_GEMM);
+            MlpArgs ma;
+            ma.X = c->xb; ma.ldx = d; ma.ln_stat = c->enc_stat; ma.W1 = L.fc1_wf; ma.s1 = L.fc1_s; ma.c1 = L.fc1_c; ma.W2 = L.fc2_w; ma.b2 = L.fc2_b;
+            ma.Xres = c->x; ma.ldr = d; ma.xb_out = c->xb; ma.stats_out = c->enc_part; ma.stats_rows = rows; ma.row_shift = c->enc_shift;
+            ma.M = (int)rows; ma.d = (int)d; ma.F = (int)F;
+            CTX_LAUNCH(c, wh_launch_enc_mlp(s, ma));
+            finish_stats();
+            continue;
+        }
         {   // fc1 + GELU (MX: the output leaves as e4m3 codes + block exponents, fc2's operand)
             Prof p(c, WH_KG_ENC_GEMM);
             GemmArgs g;
@@ -830,7 +840,16 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     const size_t o_melstage = cv.take(C * WH_N_FRAMES * 4);
     const size_t o_melT = cv.take((B * TOK_ROWS * C + 256) * esz), o_h1 = cv.take((B * H1_ROWS * d + 256) * esz);
     const size_t o_x = cv.take(B * S * d * 4), o_xn = cv.take(B * S * d * esz), o_qk = cv.take(B * S * 2 * d * esz);
-    const size_t o_vT = cv.take(B * d * c->ldv * esz), o_att = cv.take(B * S * d * esz), o_h = cv.take(B * S * F * esz);
+    // WH_PREC_BF16 on the LDS-DMA GEMM (contexts beyond a few clips, widths it has tiles for): the encoder's LayerNorms are
+    // folded into their consumer GEMMs — decided from the model and the context, never from a call's clip count
+    // (every folded GEMM must pass wh_gemm8_applicable: rows = clips x S >= 256, V^T with M = d_model >= 256 and N = S % 4 == 0, producers
+    // with N = d_model % 64 == 0; WH_GEMM8=0 sends every GEMM to k_gemm, which has no fold — then the LayerNorm kernels run)
+    c->enc_fold = m->prec == WH_PREC_BF16 && max_batch > WH_SMALL_CTX_CLIPS && d >= 256 && (d % 64) == 0 && (F % 64) == 0 && S >= 256 && (S % 4) == 0 &&
+                  m->cross_kv_wf != nullptr && wh_gemm8_enabled() && getenv("WH_NO_ENC_FOLD") == nullptr;
+    // ... and a layer's feed-forward block runs as one launch (wh_mlp.hip: d_model 512, ffn a multiple of 128); the 2048-wide hidden activations
+    // then never exist in HBM and their buffer (12.6 GB at 2048 clips) is not carved.  WH_ENC_MLP=0: the two k_gemm8 launches (A/B runs)
+    c->enc_mlp = c->enc_fold && d == 512 && F >= 128 && (F % 128) == 0 && !(getenv("WH_ENC_MLP") && atoi(getenv("WH_ENC_MLP")) == 0);
+    const size_t o_vT = cv.take(B * d * c->ldv * esz), o_att = cv.take(B * S * d * esz), o_h = c->enc_mlp ? 0 : cv.take(B * S * F * esz);
     const size_t o_enc = cv.take(B * S * d * esz), o_encf = cv.take(B * S * d * 4);
     // Cross-attention on the encoder states (bf16, whisper-base geometry, contexts of at least one workgroup per CU): the token
     // loop streams the S x d states themselves instead of the projected K and V of every layer — no cross-K/V cache.  Decided
@@ -869,12 +888,6 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     c->mx_ok = f8 && mx_k(d) && mx_k(F) && wh_mx_ln_width((int)d) && S >= 256 && (S % 4) == 0 && getenv("WH_NO_MX") == nullptr;
     const size_t o_xn8 = c->mx_ok ? cv.take(B * S * d) : 0, o_xn8s = c->mx_ok ? cv.take(B * S * 4 * wh_mx_nkp((int)d)) : 0;
     const size_t o_h8 = c->mx_ok ? cv.take(B * S * F) : 0, o_h8s = c->mx_ok ? cv.take(B * S * 4 * wh_mx_nkp((int)F)) : 0;
-    // WH_PREC_BF16 on the LDS-DMA GEMM (contexts beyond a few clips, widths it has tiles for): the encoder's LayerNorms are
-    // folded into their consumer GEMMs — decided from the model and the context, never from a call's clip count
-    // (every folded GEMM must pass wh_gemm8_applicable: rows = clips x S >= 256, V^T with M = d_model >= 256 and N = S % 4 == 0, producers
-    // with N = d_model % 64 == 0; WH_GEMM8=0 sends every GEMM to k_gemm, which has no fold — then the LayerNorm kernels run)
-    c->enc_fold = m->prec == WH_PREC_BF16 && max_batch > WH_SMALL_CTX_CLIPS && d >= 256 && (d % 64) == 0 && (F % 64) == 0 && S >= 256 && (S % 4) == 0 &&
-                  m->cross_kv_wf != nullptr && wh_gemm8_enabled() && getenv("WH_NO_ENC_FOLD") == nullptr;
     const size_t o_xb = c->enc_fold ? cv.take(B * S * d * 2) : 0, o_epart = c->enc_fold ? cv.take((d / 64) * B * S * 2 * 4) : 0;
     const size_t o_estat = c->enc_fold ? cv.take(B * S * 2 * 4) : 0, o_eshift = c->enc_fold ? cv.take(B * S * 4) : 0, o_eshift0 = c->enc_fold ? cv.take(B * S * 4) : 0;
     const size_t o_sk = cv.take(Ld * B * H * TC * WH_HEAD_DIM * esz), o_sv = cv.take(Ld * B * H * TC * WH_HEAD_DIM * esz);
@@ -900,7 +913,7 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     char* w = c->ws;
     c->pcm = (float*)(w + o_pcm); c->raw = (float*)(w + o_raw); c->mel_stage = (float*)(w + o_melstage);
     c->melT = w + o_melT; c->h1 = w + o_h1; c->x = (float*)(w + o_x); c->xn = w + o_xn; c->qk = w + o_qk;
-    c->vT = w + o_vT; c->att = w + o_att; c->hbuf = w + o_h; c->enc_out = w + o_enc; c->enc_out_f32 = (float*)(w + o_encf);
+    c->vT = w + o_vT; c->att = w + o_att; c->hbuf = c->enc_mlp ? nullptr : w + o_h; c->enc_out = w + o_enc; c->enc_out_f32 = (float*)(w + o_encf);
     c->cross_kv = w + o_ckv; c->self_k = w + o_sk; c->self_v = w + o_sv;
     if (f8) { c->cross_kv8 = w + o_ckv8; c->kv_amax = (float*)(w + o_kvam); }
     if (c->cross_es) { c->es_E = w + o_ckv; c->cross_kv = nullptr; c->dqe = (float*)(w + o_dqe); c->dctx = w + o_dctx; c->dq32 = (float*)(w + o_dq32); }

@@ -67,6 +67,15 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 // row quadruples {0,3} and {1,2}: XOR-ing bit 1 of the chunk with bit 3 of the row makes every group hit 16 distinct slots.
 __device__ __forceinline__ int swz(int row) { return (row >> 2) & 2; }
 
+#ifdef WH_GEMM8_STAMPS   // tools/gemm8_ablate.hip only (never defined in the library build): s_memtime stamps of lane 0 of every wave into a buffer of their own
+__device__ unsigned long long* g_gemm8_stamps;   // [workgroup][wave][16]
+#define WH_STAMP(i) do { if (lane == 0) g_gemm8_stamps[((long)blockIdx.x * 8 + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define WH_STAMP_ID() do { if (lane == 0) g_gemm8_stamps[((long)blockIdx.x * 8 + wave) * 16 + 15] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492); } while (0)
+#else
+#define WH_STAMP(i) do {} while (0)
+#define WH_STAMP_ID() do {} while (0)
+#endif
+
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ __forceinline__ void store8(float* p, const f32x4& a, const f32x4& b) {   // 8 consecutive outputs
@@ -101,6 +110,8 @@ __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs
     }
     const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
     const long z = blockIdx.z;
+    WH_STAMP(0);
+    WH_STAMP_ID();
     const bf16* A = (const bf16*)g.A + z * g.a_zs;
     const bf16* W = (const bf16*)g.W + z * g.w_zs;
 
@@ -182,6 +193,7 @@ __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs
         wait_stage(0, NSLOT - 1);           // the whole ring was just issued: slots 1 .. NSLOT-1 may still be in flight
         __builtin_amdgcn_s_barrier();
         if (!(ABL & 8)) read_frags(0, 0);
+        WH_STAMP(12);
         // two k-steps per iteration so the register sets are named statically
         for (int kt = 0; kt < nk; kt += 2) {
 #pragma unroll
@@ -212,6 +224,7 @@ __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs
 #pragma unroll
         for (int t = 0; t < NSLOT - 1; t++)
             if (t < nk) stage(t, t);
+        WH_STAMP(12);
         for (int kt = 0; kt < nk; kt++) {
             wait_stage(kt, NSLOT - 2);          // in flight: stages kt .. kt+NSLOT-2
             __builtin_amdgcn_s_barrier();       // stage kt visible to all; every wave has consumed the fragments of kt-1
@@ -226,7 +239,9 @@ __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs
             }
         }
     }
+    WH_STAMP(1);
     __builtin_amdgcn_s_barrier();   // every wave is done with the ring: it becomes the output staging area
+    WH_STAMP(2);
     if ((ABL & 4) && g.M > 0) {     // keep the accumulators alive, store nothing
 #pragma unroll
         for (int i = 0; i < TM; i++)
@@ -282,6 +297,7 @@ __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs
             else if (g.wscale) rowa[i] = g.wscale[m];
         }
     }
+    WH_STAMP(3);
     // row-contiguous read-back: 8 lanes x 8 columns per row, 8 rows per wave-instruction
     const int c8 = (lane & 7) * 8, r8 = lane >> 3;
     const int n_st = nw0 + c8;
@@ -328,6 +344,7 @@ __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs
                 *reinterpret_cast<f32x4*>(&stg[(ii * 16 + fl) * EP_PITCH + j * 16 + fg * 4]) = f32x4{v[0], v[1], v[2], v[3]};
             }
         }
+        WH_STAMP(4 + 2 * pass);
         // wave-private staging: the wave's own LDS writes are ordered before its reads by the lgkmcnt wait the compiler inserts
         const int mp0 = mw0 + pass * EP_ROWS + r8;       // this lane's first row of the pass; its rows are mp0 + 8 * it
         long mb = mp0 / g.m_per, mi = mp0 % g.m_per;     // row -> (block, row in block), advanced without dividing again
@@ -384,6 +401,7 @@ __global__ __launch_bounds__(512, Geo<BN>::WAVES_PER_SIMD) void k_gemm8(GemmArgs
             mi += 8;
             if (mi >= g.m_per) { mi -= g.m_per; mb += 1; }
         }
+        WH_STAMP(5 + 2 * pass);
     }
 }
 

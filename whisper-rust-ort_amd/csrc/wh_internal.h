@@ -139,6 +139,7 @@ struct wh_ctx {
     // WH_PREC_BF16 with the encoder LayerNorms folded into their consumer GEMMs (enc_fold): the residual stream again as bf16
     // (written by the producing GEMM's epilogue; the consumers' operand), the producers' partial sums and {mean, rstd} per row
     bool enc_fold = false;
+    bool enc_mlp = false;    // ... and the feed-forward block of a layer as one launch (wh_mlp.hip) where its geometry is covered
     void* xb = nullptr;            // [B][S][d] bf16
     float* enc_part = nullptr;     // [d/64][B*S][2]
     float* enc_stat = nullptr;     // [B*S][2]

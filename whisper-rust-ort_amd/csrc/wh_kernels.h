@@ -58,6 +58,27 @@ struct GemmArgs {
     const float* row_shift = nullptr;
 };
 
+// wh_mlp.hip: the encoder layer's feed-forward block in one launch (bf16 operands, LayerNorm fold on, d_model 512)
+struct MlpArgs {
+    const void* X = nullptr;        // [M][d] bf16: the residual stream's rows minus their running offset (the previous producer's xb_out)
+    long ldx = 0;
+    const float* ln_stat = nullptr; // [M][2] {mean, rstd} of those rows (k_ln_stats)
+    const void* W1 = nullptr;       // [F][d] bf16, gamma folded in
+    const float* s1 = nullptr;      // [F] row sums of the folded weights (GemmArgs::ln_s)
+    const float* c1 = nullptr;      // [F] folded bias
+    const void* W2 = nullptr;       // [d][F] bf16
+    const float* b2 = nullptr;      // [d]
+    float* Xres = nullptr;          // [M][d] f32 residual stream, updated in place
+    long ldr = 0;
+    void* xb_out = nullptr;         // [M][d] bf16 copy of the new rows minus row_shift (may be X: a workgroup reads its own rows before it writes them)
+    float* stats_out = nullptr;     // [d / 64][stats_rows][2] partial {sum, sum of squares} per (64-column group, row)
+    long stats_rows = 0;
+    const float* row_shift = nullptr;
+    int M = 0, d = 0, F = 0;
+};
+bool wh_enc_mlp_applicable(const MlpArgs& a);
+int wh_launch_enc_mlp(hipStream_t s, const MlpArgs& a);
+
 struct SkinnyArgs {
     const void* X = nullptr;   // activations, k-slab-major [K/32][x_mpad][32] (compute dtype)
     int x_mpad = 64;
