@@ -98,5 +98,19 @@ int main(int argc, char** argv) {
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms / reps * 1e3, tf = 4.0 * M * d * F / us * 1e-6;
     printf("k_enc_mlp, %d rows: %.1f us per launch (%.0f TFLOP/s); the two k_gemm8 launches it replaces: tools/gemm8_ablate (fc1 BN 128 + fc2 BN 256)\n", M, us, tf);
+    auto time_variant = [&](auto kern, const char* what) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        const dim3 grid((unsigned)((M + FM - 1) / FM));
+        hipLaunchKernelGGL(kern, grid, dim3(512), LDS_BYTES, 0, a);
+        (void)hipEventRecord(e0, 0);
+        for (int i = 0; i < reps; i++) hipLaunchKernelGGL(kern, grid, dim3(512), LDS_BYTES, 0, a);
+        (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+        float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
+        printf("   %s: %.1f us\n", what, t / reps * 1e3);
+    };
+    time_variant(k_enc_mlp<0>, "the library's form again");
+    time_variant(k_enc_mlp<1>, "no epilogue");
+    time_variant(k_enc_mlp<2>, "no GELU / fold arithmetic");
+    time_variant(k_enc_mlp<3>, "neither");
     return 0;
 }
