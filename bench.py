@@ -443,6 +443,7 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     cross_es_mode = ctxs[0].cross_mode == 1
+    placement = ctxs[0].placement   # (before the contexts are closed) the start-up step that looks where the workspace lies: DESIGN.md section 5e
     if dist is not None:
         from whisper_rust_ort_amd import sharding
         dev_t = "cuda" if backend == "nccl" else "cpu"
@@ -690,6 +691,7 @@ def main() -> None:
             "batch256": b256,
             "batch1024": b1024,
             "host_resident": host_res,
+            "workspace_placement": placement,
             "in_tolerance": in_tol,
             "scaling_weak": {"clips_per_gpu": a.clips, "total_clips_per_step": a.clips * world, "ms_per_step": ms_per_step, "value": audio_s / elapsed} if scaling == "weak" else None,
             "scaling_strong": strong if scaling == "weak" else {"total_clips_per_step": a.clips * world, "clips_per_gpu": a.clips, "ms_per_step": ms_per_step, "value": audio_s / elapsed},

@@ -30,7 +30,7 @@ STATUS = {0: "WH_OK", 1: "WH_ERR_EMPTY_AUDIO", 2: "WH_ERR_BAD_SHAPE", 3: "WH_ERR
 
 # every symbol include/whisper_hip.h declares
 EXPORTS = ("wh_model_load", "wh_model_create", "wh_model_free", "wh_model_get_dims", "wh_model_precision",
-           "wh_model_export_tensor", "wh_ctx_create", "wh_ctx_create_ex", "wh_ctx_free", "wh_ctx_cross_mode", "wh_last_error", "wh_get_timings",
+           "wh_model_export_tensor", "wh_ctx_create", "wh_ctx_create_ex", "wh_ctx_free", "wh_ctx_cross_mode", "wh_ctx_placement", "wh_last_error", "wh_get_timings",
            "wh_mel_frames", "wh_log_mel", "wh_encode", "wh_decode_greedy", "wh_decode_greedy_batch", "wh_decode_greedy_rows", "wh_transcribe_batch",
            "wh_transcribe_batch_next", "wh_transcribe_batch_device", "wh_transcribe_batch_device_next", "wh_longform_plan", "wh_transcribe_longform", "wh_profile_enable",
            "wh_profile_get", "wh_synthetic_weights", "wh_e4m3_quantize", "wh_e4m3_dequantize", "wh_abi_version",
@@ -111,6 +111,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     L.wh_ctx_free.argtypes = [vp]
     L.wh_ctx_free.restype = None
     L.wh_ctx_cross_mode.argtypes = [vp]
+    L.wh_ctx_placement.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.wh_last_error.argtypes = [vp]
     L.wh_last_error.restype = C.c_char_p
     L.wh_get_timings.argtypes = [vp, C.POINTER(WhTiming)]
@@ -255,6 +256,13 @@ class Context:
     def cross_mode(self) -> int:
         """0: the token loop streams the projected cross K / V of every layer; 1: the encoder states (wh_cross_es.hip)."""
         return int(self.lib.wh_ctx_cross_mode(self.h))
+
+    @property
+    def placement(self) -> dict:
+        """wh_ctx_placement: how many workspaces wh_ctx_create_ex timed (0: step not taken) and the cross-attention launch time on the first / kept one."""
+        a, b = C.c_float(0), C.c_float(0)
+        n = int(self.lib.wh_ctx_placement(self.h, C.byref(a), C.byref(b)))
+        return {"workspaces_timed": n, "first_us_per_launch": float(a.value), "kept_us_per_launch": float(b.value)}
 
     # --- the reference's three functions -----------------------------------------------------
     def whisper_log_mel(self, audio_16k: np.ndarray) -> np.ndarray:
@@ -482,6 +490,13 @@ class HipRuntime:
         self.check(self.lib.hipMalloc(C.byref(p), arr.nbytes), "hipMalloc")
         self.check(self.lib.hipMemcpy(p, arr.ctypes.data_as(C.c_void_p), arr.nbytes, 1), "hipMemcpy H2D")
         self.check(self.lib.hipDeviceSynchronize(), "hipDeviceSynchronize")
+        return p.value
+
+    def malloc(self, dev: int, nbytes: int) -> int:
+        """Uninitialised device memory (probe programs: a placeholder that makes the next allocation land elsewhere)."""
+        self.check(self.lib.hipSetDevice(dev), "hipSetDevice")
+        p = C.c_void_p()
+        self.check(self.lib.hipMalloc(C.byref(p), int(nbytes)), "hipMalloc")
         return p.value
 
     def free(self, ptr: int):

@@ -254,11 +254,22 @@ void launch_tile(hipStream_t s, const SkinnyArgs& a) {
 
 template <typename T, typename TO>
 void launch_by_shape(hipStream_t s, const SkinnyArgs& a) {
-    // 128-column tiles while they give at least ~128 workgroups (wide N: QKV, fc1), else 64-column tiles (N = d_model at 2048 rows: 128 workgroups)
-    const long wg128 = (long)((a.N + 127) / 128) * ((a.M + BM - 1) / BM) * a.zn;
+    // Column-tile width.  A 2048-row call has 16 row tiles, so its grid is 16 x N / BN workgroups of four waves: fp16 limb pairs (measured at 2048 clips,
+    // tools/runs/gpu_r04y.sh: decode GEMM group 197.3 ms with the bf16 rule below, 189.1 with 64 columns everywhere, 172.5 with 32 columns for
+    // N <= 512 and 64 beyond) take the narrowest tile that still fills the chip — N = d_model: 256 workgroups instead of 128 on 256 CUs;
+    // bf16 (64-byte LDS rows: a 32-column tile would be half an LDS-DMA instruction per wave): 128 columns while they give ~128 workgroups, else 64.
+    static const int force = getenv("WH_DEC_TILE_BN") ? atoi(getenv("WH_DEC_TILE_BN")) : 0;   // (A/B runs: 64 / 128 everywhere)
     constexpr int NS = sizeof(typename FragT<T>::type) <= 16 ? 4 : 3;   // ring slots: 16 / 12 KiB per slot in bf16, 32 / 24 KiB with fp16 limbs
-    if (wg128 >= 128 && a.N >= 128) launch_tile<T, TO, 128, NS>(s, a);
-    else launch_tile<T, TO, 64, NS>(s, a);
+    const long wg128 = (long)((a.N + 127) / 128) * ((a.M + BM - 1) / BM) * a.zn;
+    if (force == 64) { launch_tile<T, TO, 64, NS>(s, a); return; }
+    if (force == 128 && a.N >= 128) { launch_tile<T, TO, 128, NS>(s, a); return; }
+    if constexpr (sizeof(typename FragT<T>::type) > 16) {
+        if ((long)((a.N + 63) / 64) * ((a.M + BM - 1) / BM) * a.zn < 256) launch_tile<T, TO, 32, NS>(s, a);
+        else launch_tile<T, TO, 64, NS>(s, a);
+    } else {
+        if (wg128 >= 128 && a.N >= 128) launch_tile<T, TO, 128, NS>(s, a);
+        else launch_tile<T, TO, 64, NS>(s, a);
+    }
 }
 
 }  // namespace

@@ -153,6 +153,9 @@ struct wh_ctx {
     bool cross_es = false;
     void* es_E = nullptr;
     int es_rows = 0;            // rows from one clip's states to the next in es_E (>= n_audio_ctx)
+    // workspace placement step of wh_ctx_create_ex: workspaces timed (0: step not taken), the cross-attention launch time on the first and on the kept one
+    int place_tries = 0;
+    float place_us_first = 0.0f, place_us_kept = 0.0f;
     int es_rows_cap = 0;        // rows per clip the buffer was sized for
     float* dq32 = nullptr;      // [B][d] f32 cross-attention queries (pre-scaled)
     float* dqe = nullptr;
