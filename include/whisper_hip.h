@@ -158,8 +158,8 @@ void wh_ctx_free(wh_ctx* c);
  * token, the reference's present.{i}.encoder.{key,value}, src/main.rs:771-787), 1 = the encoder states (Ld S d), -1 = c is NULL */
 int wh_ctx_cross_mode(const wh_ctx* c);
 /* Workspace placement (contexts that run the encoder-state cross-attention at >= 1024 clips): wh_ctx_create_ex times that kernel on the fresh
- * workspace and, when it reads slow, builds a second workspace while the first is held and keeps the faster (the kernel's launch time depends on
- * where the workspace lies).  Returns the number of workspaces timed (0: step not taken; WH_PLACE=0 disables it), and the
+ * workspace and, when it reads slow, builds further workspaces (three in all at most) while the earlier ones are held and keeps the fastest (the
+ * kernel's launch time depends on where the workspace lies).  Returns the number of workspaces timed (0: step not taken; WH_PLACE=0 disables it), and the
  * microseconds per launch on the first and on the kept workspace.  No counterpart in the reference (ONNX Runtime owns its arena). */
 int wh_ctx_placement(const wh_ctx* c, float* first_us, float* kept_us);
 const char* wh_last_error(const wh_ctx* c); /* c == NULL: last load/create error of this thread */

@@ -386,11 +386,11 @@ def test_workspace_placement_step(gpu, monkeypatch):
     ref = [t.tolist() for t in small.transcribe_batch(clips, wb.DecodeParams(prompt, 6, eot, [eot]))]
     assert small.placement["workspaces_timed"] == 0
     small.close()
-    monkeypatch.setenv("WH_PLACE_FRAC", "2.0")          # no workspace can read that fast: the second one is always built and the faster kept
+    monkeypatch.setenv("WH_PLACE_FRAC", "2.0")          # no workspace can read that fast: every allowed try is made and the fastest kept
     big = wb.Context(model, 1024)
     pl = big.placement
-    print("placement step, 1024-clip bf16 context, forced second workspace:", pl)
-    assert pl["workspaces_timed"] == 2 and 0.0 < pl["kept_us_per_launch"] <= pl["first_us_per_launch"]
+    print("placement step, 1024-clip bf16 context, every try forced:", pl)
+    assert pl["workspaces_timed"] == 3 and 0.0 < pl["kept_us_per_launch"] <= pl["first_us_per_launch"]
     # 1024 clips x 1520 rows x 1 KB per launch: between a third of the HBM roof and the roof
     gbps = 1024 * 1520 * 1024 / pl["kept_us_per_launch"] * 1e-3
     assert 2500.0 < gbps < 8000.0, gbps
