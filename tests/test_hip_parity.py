@@ -396,6 +396,16 @@ def test_workspace_placement_step(gpu, monkeypatch):
     assert 2500.0 < gbps < 8000.0, gbps
     got = [t.tolist() for t in big.transcribe_batch(clips, wb.DecodeParams(prompt, 6, eot, [eot]))]
     big.close()
+    # more tries than workspaces fit: the search ends at the allocation that fails, and that failure must not surface later
+    # (a sticky HIP error found by the next hipGetLastError() made the first transcribe call of such a context fail)
+    monkeypatch.setenv("WH_PLACE_TRIES", "64")
+    many = wb.Context(model, 1024)
+    pl = many.placement
+    print("placement step, tries until the memory is full:", pl)
+    assert 3 <= pl["workspaces_timed"] < 64
+    assert [t.tolist() for t in many.transcribe_batch(clips, wb.DecodeParams(prompt, 6, eot, [eot]))] == got
+    many.close()
+    monkeypatch.delenv("WH_PLACE_TRIES")
     monkeypatch.setenv("WH_PLACE", "0")
     off = wb.Context(model, 1024)
     assert off.placement["workspaces_timed"] == 0

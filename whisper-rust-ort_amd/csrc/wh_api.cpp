@@ -1017,7 +1017,11 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     std::vector<wh_ctx*> others;
     while (tries < max_tries) {
         wh_ctx* cn = nullptr;
-        if (ctx_create_impl(m, opts, &cn) != WH_OK) break;   // (no room: what we have stays)
+        if (ctx_create_impl(m, opts, &cn) != WH_OK) {   // no room: what we have stays — and the failed allocation must not be found by a later hipGetLastError()
+            (void)hipGetLastError();
+            wh_set_error("%s", "");
+            break;
+        }
         const float tn = probe_cross_es_us(cn);
         tries++;
         if (tn > 0.0f && tn < 0.98f * t_best) {
