@@ -207,7 +207,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clips", type=int, default=0,
                     help="clips per GPU per step (one device batch resident in HBM); default: the library's largest batch for the preset — "
-                         "2048 for whisper-base (≈72 GB of workspace + caches in bf16, ≈125 GB in the f16x3 mode), 256 for whisper-large-v3 (≈99 GB); "
+                         "2048 for whisper-base (≈60 GB of workspace + caches in bf16, ≈125 GB in the f16x3 mode; a context of 1024 clips and more may hold a second or third workspace for a moment while it is created: the placement step, DESIGN.md 5f), 256 for whisper-large-v3 (≈99 GB); "
                          "a quarter of that in the exact-f32 mode")
     ap.add_argument("--total-clips", type=int, default=0,
                     help="strong scaling (BASELINE configs[2]/[4]: '512 clips sharded over N GPUs'): the whole job's clips per step, "
