@@ -28,7 +28,8 @@
 //     not: 12 MB pass an XCD's 4 MB L2 between two reads of a line) — the main loop sits on that stream; GELU adds ~250 us, the epilogue ~310.
 //     Built, measured and not adopted (tools/attic/enc_mlp_gelu_pieces.hip.txt): GEMM1 as 16 rows x 128 hidden units per wave with the GELU in
 //     four pieces beside GEMM2's stages (2,377 us: nine fragment reads per eight MFMAs, and the GELU's VALU time does not hide); GEMM2 stages as
-//     whole 128-byte lines [256 n][64 k] (2,384 us); the next stage's LDS-DMA issue ahead of the MFMAs (equal within the run-to-run spread).
+//     whole 128-byte lines [256 n][64 k] (2,384 us); the next stage's LDS-DMA issue ahead of the MFMAs, and the epilogue's residual rows requested
+//     two row tiles ahead of their use (both equal within the run-to-run spread: the epilogue waits on the issue of its stores, not on its loads).
 //   * epilogue: bias + f32 residual (in place on the residual stream), the row again as bf16 minus its running offset, partial {sum, sum of
 //     squares} per (64-column group, row) for k_ln_stats — k_gemm8's LayerNorm-producer contract (GemmArgs::xb_out / stats_out / row_shift).
 #include <stdlib.h>
