@@ -112,5 +112,7 @@ int main(int argc, char** argv) {
     time_variant(k_enc_mlp<1>, "no epilogue");
     time_variant(k_enc_mlp<2>, "no GELU / fold arithmetic");
     time_variant(k_enc_mlp<3>, "neither");
+    time_variant(k_enc_mlp<4>, "bf16 copy as 8-byte stores (the first form of the epilogue)");
+    time_variant(k_enc_mlp<0>, "the library's form, third reading");
     return 0;
 }

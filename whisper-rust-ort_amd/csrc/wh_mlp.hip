@@ -61,7 +61,8 @@ __device__ __forceinline__ int swz_a(int row) { return (row >> 1) & 7; }   // 12
 __device__ __forceinline__ int swz_b(int row) { return (row >> 2) & 2; }   // 64-byte rows (wh_gemm8.hip)
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// ABL (tools/mlp_check.hip only; 0 in the library): 1 = no epilogue (accumulators kept alive), 2 = no GELU / fold arithmetic (plain conversion)
+// ABL (tools/mlp_check.hip only; 0 in the library): 1 = no epilogue (accumulators kept alive), 2 = no GELU / fold arithmetic (plain conversion),
+// 4 = the bf16 copy as 8-byte stores (the first form of the epilogue)
 template <int ABL = 0>
 __global__ __launch_bounds__(512, 2) void k_enc_mlp(MlpArgs a) {
     extern __shared__ __attribute__((aligned(128))) char smem[];
@@ -265,14 +266,32 @@ __global__ __launch_bounds__(512, 2) void k_enc_mlp(MlpArgs a) {
         const float sh = a.row_shift ? a.row_shift[mr] : 0.0f;
         bf16* xbr = (bf16*)a.xb_out + mr * a.ldx + wn * 128 + fg * 4;
         float s1[2] = {0.0f, 0.0f}, s2[2] = {0.0f, 0.0f};
+        // the bf16 copy leaves as 16-byte stores: a lane holds 4 columns (8 bytes) of column tile j and of tile j + 1; v_permlane16_swap trades the
+        // odd lane groups' tile-j halves for the even groups' tile-(j + 1) halves, after which lane group fg holds 8 consecutive columns of tile
+        // j + (fg & 1) (columns 8 (fg >> 1) ..): half the store instructions of the 8-byte form (ABL & 4), whose issue is what the epilogue waits on
+        wh_u32x2 pk[TN2];
 #pragma unroll
         for (int j = 0; j < TN2; j++) {
             f32x4 v = acc2[i][j] + b2v[j] + rr[j];
             if (ok) *reinterpret_cast<f32x4*>(xr + j * 16) = v;
             v -= sh;
-            if (ok) *reinterpret_cast<bf16x4*>(xbr + j * 16) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            const bf16x4 b = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            if (ABL & 4) { if (ok) *reinterpret_cast<bf16x4*>(xbr + j * 16) = b; }
+            else __builtin_memcpy(&pk[j], &b, 8);
 #pragma unroll
             for (int e = 0; e < 4; e++) { s1[j >> 2] += v[e]; s2[j >> 2] += v[e] * v[e]; }
+        }
+        if (!(ABL & 4)) {
+#pragma unroll
+            for (int j = 0; j < TN2; j += 2) {
+                // D = tile j, S = tile j + 1: new D = [D.row0, S.row0, D.row2, S.row2], new S = [D.row1, S.row1, D.row3, S.row3] (rows = lane groups)
+                const wh_u32x2 lo = __builtin_amdgcn_permlane16_swap(pk[j].x, pk[j + 1].x, false, false);
+                const wh_u32x2 hi = __builtin_amdgcn_permlane16_swap(pk[j].y, pk[j + 1].y, false, false);
+                // even groups: (D', S') = (own tile-j columns 4 fg .., the next group's 4 (fg + 1) ..); odd groups: (the previous group's tile-(j+1) columns, own)
+                const wh_u32x4 w = {lo.x, hi.x, lo.y, hi.y};
+                bf16* dst = (bf16*)a.xb_out + mr * a.ldx + wn * 128 + (j + (fg & 1)) * 16 + (fg >> 1) * 8;
+                if (ok) *reinterpret_cast<wh_u32x4*>(dst) = w;
+            }
         }
 #pragma unroll
         for (int g = 0; g < 2; g++) {   // the four lanes (fg) of a row -> one partial per (64-column group, row)
