@@ -613,7 +613,8 @@ def main() -> None:
         traffic = None
         traffic_stamp = None
         # the dominant kernel's variants: e4m3 cache (fp8 mode), one workgroup per 256-column group (wide models), all heads per workgroup
-        dom_kernel = ("k_dec_cross_attn_es2" if (cross_es and prec == wb.WH_PREC_F16X3) else "k_dec_cross_attn_es" if cross_es else "k_dec_cross_attn8" if prec == wb.WH_PREC_FP8 else
+        dom_kernel = ("k_dec_cross_attn_es2" if (cross_es and prec == wb.WH_PREC_F16X3) else "k_dec_cross_attn_es8" if (cross_es and prec == wb.WH_PREC_FP8) else
+                      "k_dec_cross_attn_es" if cross_es else "k_dec_cross_attn8" if prec == wb.WH_PREC_FP8 else
                       "k_dec_cross_attn_cg" if (prec == wb.WH_PREC_BF16 and dims.d_model > 512 and dims.d_model % 256 == 0) else "k_dec_cross_attn")
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):   # HBM bytes per launch from rocprofv3 --pmc passes (see profiles/README.md)

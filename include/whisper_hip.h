@@ -139,8 +139,8 @@ int wh_ctx_create(wh_model* m, int max_batch, wh_ctx** out);
  * bits are n compute units spread evenly over the 8 XCDs.  words == 0: the stream may use the whole chip. */
 #define WH_CTX_TWO_STREAMS 1 /* separate encoder / decode streams even without CU masks */
 /* Cross-attention of the token loop computed on the encoder states themselves instead of the per-layer projected K / V
- * (bf16 models of whisper-base geometry; algebraically the same attention, half the bytes streamed per token and no
- * cross-K/V cache).  Default: on for contexts of max_batch >= 256.  _ON on a model without the geometry is refused. */
+ * (models of whisper-base geometry in the bf16, split-fp16 and fp8 modes — the states as bf16 rows, fp16 limb planes or e4m3 rows; algebraically
+ * the same attention, half the bytes streamed per token and no cross-K/V cache).  Default: on for contexts of max_batch >= 256.  _ON on a model without the geometry is refused. */
 #define WH_CTX_CROSS_ES_ON 2
 #define WH_CTX_CROSS_ES_OFF 4
 typedef struct {

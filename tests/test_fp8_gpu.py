@@ -133,9 +133,50 @@ def test_fp8_base_256_vs_64_clip_context_logit_bound(gpu, golden_dir, big):
     out-projection GEMM (64-clip context); per-clip K/V scales keep clips independent.  Teacher-forced, per-row bound."""
     from test_hip_parity import _ctx_logit_compare
     d_ctx, e256, e64, e3 = _ctx_logit_compare(wb.WH_PREC_FP8, golden_dir, "fp8", big)
-    assert d_ctx.max() < 0.15
+    # since round 4 the big contexts attend over e4m3 ENCODER STATES (k_dec_cross_attn_es8) while the 64-clip context keeps e4m3 K / V: two
+    # different quantisation points of the same attention, each about as far from the f32 vectors as the other (CPU experiment on HF whisper-base
+    # dims: max |dlogit| 0.26 with e4m3 states, 0.22 with e4m3 K / V) — their mutual distance is bounded by the sum
+    assert d_ctx.max() < 0.6
     # e4m3 weights + e4m3 cross K/V against the f32 golden vectors: reported (profiles/*fp8_accuracy*), loosely bounded here
     assert max(e256, e64, e3) < 1.5
+
+
+@pytest.mark.parametrize("nb", [32, 288])
+def test_fp8_encoder_state_form_against_projected_kv_and_golden(gpu, golden_dir, nb):
+    """Teacher-forced logits of the same clips on two contexts of ONE fp8 model — cross-attention on e4m3 encoder states (k_dec_cross_attn_es8:
+    fp8 matrix cores, queries and probabilities as e4m3 head + remainder pairs) vs on the projected e4m3 K / V — against each other and against
+    the f32 golden vectors.  32 clips: one clip per workgroup; 288: the persistent form (32 workgroups walk two clips each; every clip repeated
+    nine times must give identical rows).  The kernel itself is checked against a host restatement by tools/es8_check (below)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "es8_check")
+    if nb == 32:
+        assert os.path.exists(exe), f"{exe} missing: __graft_entry__.build() compiles it"
+        r = subprocess.run([exe, "64"], capture_output=True, text=True, timeout=300)
+        print(r.stdout)
+        assert r.returncode == 0 and "MISMATCH" not in r.stdout, r.stdout + r.stderr
+    g0 = np.load(os.path.join(golden_dir, "base_s1234_c0.npz"))
+    prompt, eot = g0["prompt"].tolist(), int(g0["eot"])
+    forced = g0["forced_c"].tolist()
+    model = wb.Model("synthetic:base:1234", 0, wb.WH_PREC_FP8)
+    distinct = [ms.synth_clip(0), ms.synth_clip(3)] + [ms.synth_clip(300 + i) for i in range(30)]
+    clips = [distinct[i % 32] for i in range(nb)]
+    fp = wb.DecodeParams(prompt, len(forced) + 1, eot, forced=forced)
+    out = {}
+    for form in (True, False):
+        ctx = wb.Context(model, nb, cross_es=form)
+        assert ctx.cross_mode == (1 if form else 0)
+        ctx.transcribe_batch(clips, wb.DecodeParams(prompt, 2, eot, [eot]))
+        t, lg = ctx.greedy_decode_resident_rows(fp, list(range(nb)) if nb <= 32 else list(range(32)) + [32, 64 + 5, nb - 1])
+        out[form] = np.stack(lg[:32])
+        if nb > 32:
+            for j, r in enumerate([32, 64 + 5, nb - 1]):
+                assert np.array_equal(lg[32 + j], out[form][r % 32]), (form, r)
+        ctx.close()
+    d = float(np.abs(out[True] - out[False]).max())
+    err = {f: max(float(np.abs(out[f][0][i][g0["top_ids_c"][i]] - g0["top_vals_c"][i]).max()) for i in range(len(forced) + 1)) for f in out}
+    print(f"fp8, {nb} clips: encoder-state form vs K / V form max |dlogit| {d:.4f}; vs f32 golden: {err[True]:.4f} (states) / {err[False]:.4f} (K / V)")
+    assert np.isfinite(out[True]).all()
+    assert err[True] < 1.5 and err[False] < 1.5 and d < 0.6
 
 
 def test_mx_kernels_match_host_restatement(gpu):

@@ -742,6 +742,11 @@ def test_cross_mode_rule_and_flags(gpu):
         c = wb.Context(basex3, mb)
         assert c.cross_mode == want, (mb, c.cross_mode)
         c.close()
+    base8 = wb.Model("synthetic:base:1234", 0, wb.WH_PREC_FP8)
+    for mb, want in ((64, 0), (256, 1)):   # the fp8 mode streams them as e4m3 rows (k_dec_cross_attn_es8)
+        c = wb.Context(base8, mb)
+        assert c.cross_mode == want, (mb, c.cross_mode)
+        c.close()
 
 
 @pytest.mark.parametrize("nb", [32, 288])

@@ -37,7 +37,7 @@ def main():
     ref_tokens = None
     # (precision, cross-attention form of the free-running batch): bf16 on the projected K / V and — the benchmarked form — on the encoder states;
     # f16x3 = the split-fp16 mode (f32 results on the fp16 matrix cores)
-    modes = (("f32", "f32", None), ("f16x3", "f16x3", None), ("bf16", "bf16", False), ("bf16_es", "bf16", True), ("fp8", "fp8", None))
+    modes = (("f32", "f32", None), ("f16x3", "f16x3", None), ("bf16", "bf16", False), ("bf16_es", "bf16", True), ("fp8", "fp8", False), ("fp8_es", "fp8", True))
     for name, prec_name, es in modes:
         model = wb.Model(f"synthetic:{a.preset}:{a.seed}", 0, wb.PRECISIONS[prec_name])
         ctx = wb.Context(model, a.clips, cross_es=es) if (es is not None and a.preset == "base") else wb.Context(model, a.clips)
@@ -87,13 +87,13 @@ def main():
 
     logit_scale = float(np.abs(forced_logits["f32"]).mean())
     out = {
-        "what": "BASELINE configs[4]: fp8 / bf16 (projected K / V and encoder-state cross-attention) / f16x3 vs exact-f32 accuracy, same library, same inputs",
+        "what": "BASELINE configs[4]: fp8 (e4m3 K / V and e4m3 encoder states) / bf16 (projected K / V and encoder-state cross-attention) / f16x3 vs exact-f32 accuracy, same library, same inputs",
         "model": f"whisper-{a.preset} dims, hash-seeded synthetic weights (seed {a.seed}) — logits of random weights are nearly flat, "
                  "so free-running agreement understates what trained weights give; the teacher-forced logit error is the transferable figure",
         "clips": a.clips, "max_new_tokens": N, "forced_clips": a.forced_clips, "mean_abs_f32_logit": logit_scale,
-        "free_running_vs_f32": {k: free_stats(free[k], ref_tokens) for k in ("f16x3", "bf16", "bf16_es", "fp8")},
+        "free_running_vs_f32": {k: free_stats(free[k], ref_tokens) for k in ("f16x3", "bf16", "bf16_es", "fp8", "fp8_es")},
         "fp8_vs_bf16_free_running": free_stats(free["fp8"], free["bf16"]),
-        "teacher_forced_vs_f32": {k: forced_stats(forced_logits[k], forced_logits["f32"]) for k in ("f16x3", "bf16", "bf16_es", "fp8")},
+        "teacher_forced_vs_f32": {k: forced_stats(forced_logits[k], forced_logits["f32"]) for k in ("f16x3", "bf16", "bf16_es", "fp8", "fp8_es")},
         "fp8_vs_bf16_teacher_forced": forced_stats(forced_logits["fp8"], forced_logits["bf16"]),
         "batch_seconds": secs,
     }

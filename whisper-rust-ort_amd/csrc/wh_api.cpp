@@ -255,7 +255,7 @@ int run_encoder(wh_ctx* c, int nb, bool want_f32) {
         Prof p(c, WH_KG_ENC_GEMM);
         // the cross K/V projection's operand: MX form when that GEMM runs on the fp8 matrix cores, else the compute dtype
         // (fold: the final LayerNorm lives in the cross K/V projection's weights; its statistics are in c->enc_stat already)
-        if (c->mx_ok) CTX_LAUNCH(c, wh_launch_layernorm_mx(s, c->x, m->enc_ln_w, m->enc_ln_b, c->xn8, c->xn8_sc, rows, (int)d));
+        if (c->mx_ok && !c->cross_es) CTX_LAUNCH(c, wh_launch_layernorm_mx(s, c->x, m->enc_ln_w, m->enc_ln_b, c->xn8, c->xn8_sc, rows, (int)d));   // (encoder-state form: the final LayerNorm runs at decode step 0, into e4m3 rows)
         else if (!fold) wh_launch_layernorm(s, prec, c->x, m->enc_ln_w, m->enc_ln_b, c->enc_out, rows, (int)d);
         if (want_f32) {
             if (prec == WH_PREC_F32) hipMemcpyAsync(c->enc_out_f32, c->enc_out, rows * d * 4, hipMemcpyDeviceToDevice, s);
@@ -371,6 +371,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
         // here, on the decode stream, into decode-side storage — the encoder-side workspace is free for the next pass afterwards
         Prof pr(c, WH_KG_DEC_GEMM);
         if (prec == WH_PREC_F16X3) wh_launch_layernorm_es2(s, c->x, m->enc_ln_w, m->enc_ln_b, c->es_E, (long)nb * S, (int)S, c->es_rows);   // fp16 limb planes
+        else if (f8) wh_launch_layernorm_es8(s, c->x, m->enc_ln_w, m->enc_ln_b, c->es_E, (long)nb * S, (int)S, c->es_rows);                 // e4m3 rows
         else wh_launch_layernorm_blocks(s, prec, c->x, m->enc_ln_w, m->enc_ln_b, c->es_E, (long)nb * S, (int)d, c->es_rows == (int)S ? 0 : (int)S, c->es_rows);
     } else {
         Prof pr(c, WH_KG_DEC_GEMM);
@@ -455,7 +456,7 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                 {   // LN2 ∘ cross-attention query, kept in f32
                     Prof pr(c, WH_KG_DEC_GEMM);
                     a = SkinnyArgs();
-                    a.X = c->dxs; a.x_mpad = mpad; a.W = L.cq_w; a.bias = L.cq_b; a.C = c->dq32; a.ldc = d; a.M = nb; a.N = (int)d; a.K = (int)d;
+                    a.X = c->dxs; a.x_mpad = mpad; a.W = L.cq_w; a.bias = L.cq_b; a.wscale = L.cq_sc; a.C = c->dq32; a.ldc = d; a.M = nb; a.N = (int)d; a.K = (int)d;
                     a.ln_part = c->lnpart; a.ln_tiles = ln_tiles_d; a.ln_s = L.cq_s; a.shift_io = c->dshift;
                     dec_gemm(true, a);
                     // expanded queries qe[h] = W_k,h^T q_h: [nb][H][d] f32
@@ -472,7 +473,8 @@ int run_decode(wh_ctx* c, int nb, const wh_decode_params* p, int64_t* tokens_out
                     a.M = nb; a.N = WH_HEAD_DIM; a.K = (int)d;
                     a.zn = D.n_heads; a.x_zs = (long)(d / 32) * mpad * 32; a.w_zs = (long)WH_HEAD_DIM * d; a.c_zs = (long)(WH_HEAD_DIM / 32) * mpad * 32;
                     a.bias_zs = WH_HEAD_DIM;
-                    dec_gemm(false, a);
+                    if (f8) wh_launch_dec_gemm(s, WH_PREC_BF16, false, a);   // (fp8 mode: cv_w is the quantised model's W_v, code x row scale, as bf16 — wh_model.cpp)
+                    else dec_gemm(false, a);
                 }
             } else {
             {   // LN2 ∘ cross-attention query
@@ -878,7 +880,8 @@ static int ctx_create_impl(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     if (const char* e = getenv("WH_ES_PAD_MAX")) c->es_rows_cap = std::max(c->es_rows, (int)S + atoi(e));   // (probe runs: room for wh_debug_set_es_pad)
     const size_t o_ckv = cv.take(c->cross_es ? B * (size_t)c->es_rows_cap * d * esz : Ld * 2 * B * S * d * esz);
     const bool f8 = m->prec == WH_PREC_FP8;
-    const size_t o_ckv8 = f8 ? cv.take(Ld * 2 * B * S * d) : 0, o_kvam = f8 ? cv.take(Ld * 2 * B * H * 4) : 0;
+    const bool f8kv = f8 && !c->cross_es;   // (the encoder-state form of the fp8 mode keeps no projected K / V at all)
+    const size_t o_ckv8 = f8kv ? cv.take(Ld * 2 * B * S * d) : 0, o_kvam = f8kv ? cv.take(Ld * 2 * B * H * 4) : 0;
     // fp8-MFMA encoder (wh_gemm8_mx.hip): MX activations when every contraction length is one the kernel takes
     // (decided from the model and the context only, never from a call's clip count: S >= 256 rows is one full tile even for one clip)
     // contraction lengths: any multiple of 128 from 256 on (whisper-large-v3: 1280, 5120); d_model must be a width k_layernorm_mx exists for
@@ -915,7 +918,7 @@ static int ctx_create_impl(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     c->melT = w + o_melT; c->h1 = w + o_h1; c->x = (float*)(w + o_x); c->xn = w + o_xn; c->qk = w + o_qk;
     c->vT = w + o_vT; c->att = w + o_att; c->hbuf = c->enc_mlp ? nullptr : w + o_h; c->enc_out = w + o_enc; c->enc_out_f32 = (float*)(w + o_encf);
     c->cross_kv = w + o_ckv; c->self_k = w + o_sk; c->self_v = w + o_sv;
-    if (f8) { c->cross_kv8 = w + o_ckv8; c->kv_amax = (float*)(w + o_kvam); }
+    if (f8kv) { c->cross_kv8 = w + o_ckv8; c->kv_amax = (float*)(w + o_kvam); }
     if (c->cross_es) { c->es_E = w + o_ckv; c->cross_kv = nullptr; c->dqe = (float*)(w + o_dqe); c->dctx = w + o_dctx; c->dq32 = (float*)(w + o_dq32); }
     if (c->enc_fold) { c->xb = w + o_xb; c->enc_part = (float*)(w + o_epart); c->enc_stat = (float*)(w + o_estat); c->enc_shift = (float*)(w + o_eshift); c->enc_shift0 = (float*)(w + o_eshift0); }
     if (c->enc_fold) {   // the first producer's row offsets: the mean of each position's row of the positional table, for every clip of a batch
@@ -1002,10 +1005,11 @@ int wh_ctx_create_ex(wh_model* m, const wh_ctx_opts* opts, wh_ctx** out) {
     if (t1 <= 0.0f) return WH_OK;
     c->place_tries = 1;
     c->place_us_first = c->place_us_kept = t1;
-    const double bytes = (double)c->max_batch * c->es_rows * m->dims.d_model * (m->prec == WH_PREC_F16X3 ? 4.0 : 2.0);
+    const double bytes = (double)c->max_batch * c->es_rows * m->dims.d_model * (m->prec == WH_PREC_F16X3 ? 4.0 : m->prec == WH_PREC_FP8 ? 1.0 : 2.0);
     const char* fe = getenv("WH_PLACE_FRAC");
     // (between the two states as the probe sees them: bf16 0.75-0.77 / 0.82-0.84 of the roof, fp16 limb planes 0.79-0.82 / 0.84-0.86)
-    const double want = fe ? atof(fe) : (m->prec == WH_PREC_F16X3 ? 0.835 : 0.80);
+    // (e4m3 states: 0.76-0.80 of the roof at one byte per element in the probe)
+    const double want = fe ? atof(fe) : (m->prec == WH_PREC_F16X3 ? 0.835 : m->prec == WH_PREC_FP8 ? 0.70 : 0.80);
     if (bytes / (t1 * 1e-6) >= want * 8e12) return WH_OK;
     // further workspaces, each built while all earlier ones still hold their memory (so it lies somewhere else), until one reads fast or
     // WH_PLACE_TRIES (default 3) are timed or the next one does not fit; the fastest stays

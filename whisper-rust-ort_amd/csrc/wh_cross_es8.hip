@@ -1,0 +1,356 @@
+// wh_cross_es8.hip — WH_PREC_FP8: decoder cross-attention of one position on the encoder states held as e4m3 (gfx950, whisper-base geometry:
+// d_model 512, 8 heads).  The algebra and the structure are wh_cross_es.hip's (reference src/main.rs:771-787, 798-812: the decoder graphs'
+// cross-attention over present.{i}.encoder.{key,value}):
+//     score_h[key] = (Wk_h^T q_h) . E[key] =: qe_h . E[key]          out_h = Wv_h (sum_key p_h[key] E[key]) + bv_h
+// with E streamed ONCE per (layer, position) for all 8 heads — here at one byte per element, half of what the fp8 mode's e4m3 K + V of every
+// layer stream (2 S d bytes) and half of the bf16 encoder-state form.  Both products run on the fp8 matrix cores:
+//
+//   scores  D[m][key] = sum_dim QE[m][dim] * E[key][dim]     v_mfma_f32_16x16x32_fp8_fp8, rows m = {fp8(qe_h) : h} ++ {fp8(16 (qe_h - hi)) : h}
+//   output  C[m][dim] = sum_key P[m][key]  * E[key][dim]     the same instruction,        rows m = {fp8(p_h) : h}  ++ {fp8(16 (p_h - hi)) : h}
+//
+// The 8 heads fill half of a 16-row tile; the other half carries the e4m3 remainders (scaled by 16 so that they stay normal numbers), and the
+// two halves are added — the second divided by 16 — where they leave the matrix core: queries and probabilities enter with ~8 significant bits
+// (what bf16 gives them in wh_cross_es.hip); the only operand at e4m3 precision is E, as K and V are in the projected form of this mode.
+//
+// One workgroup per CU (persistent, walks its clips): four computing waves + one loader wave; ring of five 32-key tiles of 16 KiB (512-byte key
+// rows; an LDS-DMA piece of 1 KiB is two rows), one barrier per tile, the software pipeline of wh_cross_es.hip (scores of tile g + 1, softmax and
+// output of tile g in one iteration).  Bank conflicts: LDS is written linearly by the DMA, so the swizzle is on the source side — 16-byte chunk p
+// of tile row r holds chunk p ^ swz(r), swz(r) = (r & 15) ^ 8 ((r >> 4) & 1): both read patterns (ds_read_b64: 8 dims of a key per lane) then
+// touch 32 distinct 8-byte units in each of the instruction's two 32-lane service groups.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "wh_common.h"
+#include "wh_kernels.h"
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int E8_D = 512, E8_H = 8, E8_TK = 32;
+constexpr int E8_ROWB = E8_D;                          // bytes per key row
+constexpr int E8_TILEB = E8_TK * E8_ROWB;              // 16 KiB
+constexpr int E8_SCP = 36;                             // floats per (dim half, limb, head) row of the score exchange (32 keys + pad)
+constexpr int E8_SCB = 4 * E8_H * E8_SCP;              // floats per score-exchange buffer: [dim half][hi | lo of the query][head][E8_SCP]
+constexpr int e8_lds(int nstage) { return nstage * E8_TILEB + 2 * E8_SCB * 4 + E8_H * E8_D * 4; }   // ring + score exchange + next queries
+constexpr float E8_LO = 16.0f, E8_LO_INV = 1.0f / 16.0f;   // scale of the remainder rows
+
+template <int N> __device__ __forceinline__ void e8_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int AUX>
+__device__ __forceinline__ void e8_glds16(const void* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, AUX);
+}
+__device__ __forceinline__ int e8_swz(int r) { return (r & 15) ^ (((r >> 4) & 1) << 3); }
+__device__ __forceinline__ float e8_ror8(float v) {    // v of lane ^ 8 (same 16-lane row): DPP row_ror:8
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+}
+__device__ __forceinline__ unsigned e8_ror8u(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true); }
+// four f32 -> four e4m3 bytes (byte u = v[u]) and back
+__device__ __forceinline__ unsigned e8_pack4(float a, float b, float c, float d) {
+    int p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
+}
+// the remainder limb of four values whose head limb is `hi`: fp8(16 (v - hi))
+__device__ __forceinline__ unsigned e8_rem4(unsigned hi, float a, float b, float c, float d) {
+    const float h0 = __builtin_amdgcn_cvt_f32_fp8((int)hi, 0), h1 = __builtin_amdgcn_cvt_f32_fp8((int)hi, 1);
+    const float h2 = __builtin_amdgcn_cvt_f32_fp8((int)hi, 2), h3 = __builtin_amdgcn_cvt_f32_fp8((int)hi, 3);
+    return e8_pack4((a - h0) * E8_LO, (b - h1) * E8_LO, (c - h2) * E8_LO, (d - h3) * E8_LO);
+}
+__device__ __forceinline__ long e8_join(unsigned lo, unsigned hi) { return (long)(((unsigned long long)hi << 32) | lo); }
+
+// qe : [B][8][512] f32 expanded queries (natural-log score units)        E: [B][e_rows][512] e4m3 encoder states (final LayerNorm applied)
+// out: ctx as the decode GEMM's operand, slab layout [8 * 512 / 32][mpad][32] bf16, column h * 512 + dim
+template <int AUX, int NSTAGE>
+__global__ __launch_bounds__(320, 1) void k_dec_cross_attn_es8(const float* __restrict__ qe, const unsigned char* __restrict__ E, bf16* __restrict__ out,
+                                                                int S, int e_rows, int mpad, int B) {
+    constexpr int LA = NSTAGE - 1;   // LA tiles staged ahead of the one being consumed
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sc = reinterpret_cast<float*>(smem + NSTAGE * E8_TILEB);   // [2 tiles][E8_SCB]
+    float* Qs = sc + 2 * E8_SCB;                                       // [8][512] f32: the next clip's expanded queries
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntile = (S + E8_TK - 1) / E8_TK;
+    const int G = gridDim.x;
+    const int n_my = (B - (int)blockIdx.x + G - 1) / G;   // clips of this workgroup
+    const int total = n_my * ntile;                        // tiles of this workgroup
+
+    if (wave >= 4) {
+        // ================================ loader ================================
+        constexpr int PPT = E8_TILEB / 1024;   // 16 pieces of 1 KiB = 2 key rows per tile
+        const int rsub = lane >> 5, pc = lane & 31;   // row inside a piece, physical 16-byte chunk of the row
+        int st_clip = blockIdx.x, st_t = 0, st_slot = 0;   // tiles are staged strictly in sequence
+        auto stage_next = [&]() {
+            char* base = smem + st_slot * E8_TILEB;
+            const unsigned char* Ec = E + (long)st_clip * e_rows * E8_ROWB;
+#pragma unroll
+            for (int j = 0; j < PPT; j++) {
+                const int r = 2 * j + rsub;
+                const int key = min(st_t * E8_TK + r, S - 1);   // rows past the clip's end re-read its last key (finite; their scores are masked)
+                e8_glds16<AUX>(Ec + (long)key * E8_ROWB + ((pc ^ e8_swz(r)) << 4), base + j * 1024);
+            }
+            st_slot = st_slot + 1 == NSTAGE ? 0 : st_slot + 1;
+            if (++st_t == ntile) { st_t = 0; st_clip += G; }
+        };
+        auto stage_q = [&](int clip) {
+            const float* src = qe + (long)clip * (E8_H * E8_D);
+#pragma unroll
+            for (int j = 0; j < 16; j++) e8_glds16<0>(src + (j * 64 + lane) * 4, reinterpret_cast<char*>(Qs) + j * 1024);
+        };
+        stage_q(blockIdx.x);
+#pragma unroll
+        for (int t = 0; t < LA; t++)
+            if (t < total) stage_next();
+        // vmcnt retires in issue order (and holds at most 63): "all but the last LA - 1 tiles' pieces" covers the queries and tile 0
+        if (total >= LA) e8_wait_vm<(PPT * (LA - 1) < 63 ? PPT * (LA - 1) : 63)>(); else e8_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();   // P1: the first clip's queries are in Qs
+        __builtin_amdgcn_s_barrier();   // P2: tile 0 is in the ring
+        int clip = blockIdx.x, t = 0;
+        for (int g = 0; g < total; g++) {
+            if (g + 1 < total) {   // tile g + 1 has landed; the younger tiles stay in flight (conservative where the next clip's queries are among them)
+                if (total - 2 - g >= LA - 2) e8_wait_vm<PPT*(LA - 2)>(); else e8_wait_vm<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            if (g + LA < total) stage_next();
+            if (t == 0 && clip + G < B) stage_q(clip + G);   // Qs was read (if at all) before this barrier
+            if (++t == ntile) { t = 0; clip += G; }
+        }
+        return;
+    }
+
+    // ================================ compute ================================
+    const int fl = lane & 15, fg = lane >> 4;
+    const int hf = wave & 1, kt = wave >> 1;
+    // ---- expanded queries of this wave's dim half as the MFMA row operand: row fl -> head fl & 7, rows 0-7 the e4m3 heads, rows 8-15 the remainders
+    long qa[8];
+    auto qa_from_lds = [&]() {
+        const float* qp = Qs + (fl & 7) * E8_D + 256 * hf + 8 * fg;
+        const bool lo = fl >= 8;
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(qp + 32 * s), b = *reinterpret_cast<const f32x4*>(qp + 32 * s + 4);
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = (u < 4 ? a[u & 3] : b[u & 3]) * 1.44269504088896341f;   // scores in log2 units: p = exp2(s - m)
+            const unsigned h0 = e8_pack4(v[0], v[1], v[2], v[3]), h1 = e8_pack4(v[4], v[5], v[6], v[7]);
+            const unsigned r0 = e8_rem4(h0, v[0], v[1], v[2], v[3]), r1 = e8_rem4(h1, v[4], v[5], v[6], v[7]);
+            qa[s] = lo ? e8_join(r0, r1) : e8_join(h0, h1);
+        }
+    };
+    // ---- scores of the tile in slot `sl` for keys 16 kt + fl over dims 256 hf ..: rows 4 fg + i of D; partials to sc buffer `buf`
+    auto score_reads = [&](int sl, long (&ef)[8]) {
+        const int r = 16 * kt + fl;
+        const char* rp = smem + sl * E8_TILEB + r * E8_ROWB + (fg & 1) * 8;
+        const int sw = e8_swz(r);
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const int c = 16 * hf + 2 * s + (fg >> 1);
+            ef[s] = *reinterpret_cast<const long*>(rp + ((c ^ sw) << 4));
+        }
+    };
+    auto score_mfma = [&](const long (&ef)[8], int buf) {
+        f32x4 d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 8; s += 2) {
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(qa[s], ef[s], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(qa[s + 1], ef[s + 1], d1, 0, 0, 0);
+        }
+        // rows 0-7 (lane groups 0, 1) carry the head limbs, rows 8-15 (groups 2, 3) the remainders: both go to the exchange buffer as they are
+        float* dst = sc + buf * E8_SCB + ((hf * 2 + (fg >> 1)) * E8_H + 4 * (fg & 1)) * E8_SCP + 16 * kt + fl;
+#pragma unroll
+        for (int i = 0; i < 4; i++) dst[i * E8_SCP] = d0[i] + d1[i];
+    };
+
+    f32x4 acc[8];   // rows 4 fg + i: heads 4 (fg & 1) + i; lane groups 0, 1 from the probabilities' head limbs, 2, 3 from their remainders
+    float m_run = -INFINITY, l_run = 0.0f;
+    const int kb = 16 * (fg & 1) + 8 * (fg >> 1);   // first key (within a tile) of this lane's contraction slots
+    int clip = blockIdx.x, t = 0, slot = 0;          // the tile being consumed: tile t of `clip`, ring slot `slot`
+
+    __builtin_amdgcn_s_barrier();   // P1
+    qa_from_lds();
+    __builtin_amdgcn_s_barrier();   // P2
+    {   // scores of tile 0
+        long ef[8];
+        score_reads(0, ef);
+        score_mfma(ef, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc[e] = f32x4{0, 0, 0, 0};
+    for (int g = 0; g < total; g++) {
+        const bool more = g + 1 < total;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // tile g + 1 and the scores of tile g visible to all; every wave is done with tile g - 1
+        const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
+        // the next clip's first tile is scored with the next clip's queries (in Qs since a clip ago)
+        if (t == ntile - 1 && more) qa_from_lds();
+        const char* tb = smem + slot * E8_TILEB;
+        // ---- every LDS read of this iteration up front, in the order of use: scores of tile g (softmax), score operands of tile g + 1,
+        // the 8 x 8 blocks of tile g (output).  Lanes fl and fl + 8 share a head: each takes four of the lane group's eight keys
+        const int h = fl & 7, kq = kb + 4 * (fl >> 3);
+        const float* s0 = sc + (g & 1) * E8_SCB + h * E8_SCP + kq;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(s0), a1 = *reinterpret_cast<const f32x4*>(s0 + E8_H * E8_SCP);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(s0 + 2 * E8_H * E8_SCP), b1 = *reinterpret_cast<const f32x4*>(s0 + 3 * E8_H * E8_SCP);
+        long ef[8];
+        if (more) score_reads(nslot, ef);
+        wh_u32x2 blk[8];
+        {
+            const int c = 8 * wave + (fl >> 1);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int r = kb + j;
+                blk[j] = *reinterpret_cast<const wh_u32x2*>(tb + r * E8_ROWB + ((c ^ e8_swz(r)) << 4) + (fl & 1) * 8);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads above the arithmetic below
+        // ---- online softmax of tile g: lane -> head fl & 7, keys kb .. kb + 7 of the tile (identical in the four waves)
+        long pa;
+        {
+            float sv[4];
+            float tmax = -INFINITY;
+            const int key0 = t * E8_TK + kq;
+#pragma unroll
+            for (int u = 0; u < 4; u++) sv[u] = (a0[u] + b0[u]) + (a1[u] + b1[u]) * E8_LO_INV;   // two dim halves x {head limb, remainder / 16}
+            if (t == ntile - 1) {   // (wave-uniform) keys past the end of the clip
+#pragma unroll
+                for (int u = 0; u < 4; u++) sv[u] = (key0 + u < S) ? sv[u] : -INFINITY;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) tmax = fmaxf(tmax, sv[u]);
+            tmax = fmaxf(tmax, e8_ror8(tmax));   // the head's other four keys of this lane group
+            tmax = xrow_max(tmax);               // over the four lane groups: all 32 keys of the tile
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
+            float ps = 0.0f;
+            float pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                pv[u] = __builtin_amdgcn_exp2f(sv[u] - m_new);   // masked key: exp2(-inf) = 0
+                ps += pv[u];
+            }
+            // operand rows 0-7: e4m3(p) of keys kb .. kb + 7 (this lane's four and, through DPP, its partner's); rows 8-15: their remainders x 16
+            {
+                const unsigned own_hi = e8_pack4(pv[0], pv[1], pv[2], pv[3]);
+                const unsigned own_lo = e8_rem4(own_hi, pv[0], pv[1], pv[2], pv[3]);
+                const unsigned oth_hi = e8_ror8u(own_hi), oth_lo = e8_ror8u(own_lo);
+                // lane fl < 8 (row h) owns keys kb .. kb + 3, lane fl + 8 (row 8 + h) keys kb + 4 .. kb + 7
+                pa = fl < 8 ? e8_join(own_hi, oth_hi) : e8_join(oth_lo, own_lo);
+            }
+            l_run = l_run * alpha + ps;
+            m_run = m_new;
+            // head h's factor sits in lane h: through SGPRs (v_readlane), and only when some running maximum moved (wave-uniform)
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+                float ah[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) ah[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), q));
+                const bool up = fg & 1;
+                const float a4[4] = {up ? ah[4] : ah[0], up ? ah[5] : ah[1], up ? ah[6] : ah[2], up ? ah[7] : ah[3]};
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc[e][i] *= a4[i];
+                }
+            }
+        }
+        // ---- scores of tile g + 1 (independent of everything above: fills the matrix pipe while the VALU transposes)
+        if (more) score_mfma(ef, (g + 1) & 1);
+        // ---- output of tile g: dims 128 wave + 8 fl + e, contraction over the tile's 32 keys.  The 8 keys x 8 dims block of bytes is
+        // transposed in registers: byte pairs of key pairs first (16 v_perm_b32), then the four keys of a contraction half (16 more)
+        {
+            unsigned w[4][4];   // w[q][m]: {key 2q dim 2m, key 2q+1 dim 2m, key 2q dim 2m+1, key 2q+1 dim 2m+1}
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                w[q][0] = __builtin_amdgcn_perm(blk[2 * q + 1].x, blk[2 * q].x, 0x05010400u);
+                w[q][1] = __builtin_amdgcn_perm(blk[2 * q + 1].x, blk[2 * q].x, 0x07030602u);
+                w[q][2] = __builtin_amdgcn_perm(blk[2 * q + 1].y, blk[2 * q].y, 0x05010400u);
+                w[q][3] = __builtin_amdgcn_perm(blk[2 * q + 1].y, blk[2 * q].y, 0x07030602u);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const unsigned sel = (e & 1) ? 0x07060302u : 0x05040100u;
+                const unsigned k03 = __builtin_amdgcn_perm(w[1][e >> 1], w[0][e >> 1], sel);   // keys kb .. kb + 3 of dim e
+                const unsigned k47 = __builtin_amdgcn_perm(w[3][e >> 1], w[2][e >> 1], sel);   // keys kb + 4 .. kb + 7
+                acc[e] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pa, e8_join(k03, k47), acc[e], 0, 0, 0);
+            }
+        }
+        slot = nslot;
+        if (++t < ntile) continue;
+        // ---- the clip ends: rows h and 8 + h (lanes l and l ^ 32) are the head limb's and the remainder's share of head h — add, normalise, store
+        {
+            const float lh = l_run + e8_ror8(l_run);   // the head's two key quartets
+            const float inv = 1.0f / xrow_sum(lh);
+            float ih[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) ih[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv), q));
+            const bool up = fg & 1;
+            const float inv4[4] = {up ? ih[4] : ih[0], up ? ih[5] : ih[1], up ? ih[6] : ih[2], up ? ih[7] : ih[3]};
+            const float wgt = fg < 2 ? 1.0f : E8_LO_INV;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                bf16x8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float mine = acc[e][i] * wgt;
+                    const wh_u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine), __float_as_uint(mine), false, false);
+                    ov[e] = (bf16)((__uint_as_float(sw.x) + __uint_as_float(sw.y)) * inv4[i]);
+                }
+                if (fg < 2) {
+                    const int k = (4 * fg + i) * E8_D + 128 * wave + 8 * fl;
+                    *reinterpret_cast<bf16x8*>(out + ((long)(k >> 5) * mpad + clip) * 32 + (k & 31)) = ov;
+                }
+            }
+        }
+        // the next clip starts from nothing
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] = f32x4{0, 0, 0, 0};
+        m_run = -INFINITY;
+        l_run = 0.0f;
+        t = 0;
+        clip += G;
+    }
+}
+
+// encoder final LayerNorm -> e4m3 rows [B][e_rows][512] (the states as the kernel above streams them): one wave per row
+__global__ __launch_bounds__(256) void k_layernorm_es8(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       unsigned char* __restrict__ out, long rows, int S, int e_rows) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* xr = x + r * E8_D + lane * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(xr), b = *reinterpret_cast<const f32x4*>(xr + 4);
+    float s = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 4; u++) s += a[u] + b[u];
+    const float mean = wave_sum(s) * (1.0f / E8_D);
+    float q = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 4; u++) { q += (a[u] - mean) * (a[u] - mean); q += (b[u] - mean) * (b[u] - mean); }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / E8_D) + 1e-5f);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + lane * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + lane * 8 + 4);
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(beta + lane * 8), c1 = *reinterpret_cast<const f32x4*>(beta + lane * 8 + 4);
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { v[u] = (a[u] - mean) * rstd * g0[u] + c0[u]; v[4 + u] = (b[u] - mean) * rstd * g1[u] + c1[u]; }
+    const wh_u32x2 o = {e8_pack4(v[0], v[1], v[2], v[3]), e8_pack4(v[4], v[5], v[6], v[7])};
+    const long clip = r / S, key = r % S;
+    *reinterpret_cast<wh_u32x2*>(out + (clip * e_rows + key) * E8_D + lane * 8) = o;
+}
+
+}  // namespace
+
+// (two workgroups per CU with rings of three tiles were measured: 419 vs 324 us per 2048-clip launch — the shallow rings starve the stream)
+void wh_launch_dec_cross_attn_es8(hipStream_t s, const float* qe, const void* E, void* out, int S, int e_rows, int B, int mpad, bool stream_nt, int n_cus) {
+    if (n_cus <= 0) n_cus = 256;
+    const int grid = std::min(B, n_cus);   // one workgroup per CU walks its clips
+    if (stream_nt) {
+        wh_ensure_dyn_lds((const void*)k_dec_cross_attn_es8<2, 5>, e8_lds(5));
+        hipLaunchKernelGGL((k_dec_cross_attn_es8<2, 5>), dim3(grid), dim3(320), e8_lds(5), s, qe, (const unsigned char*)E, (bf16*)out, S, e_rows, mpad, B);
+    } else {
+        wh_ensure_dyn_lds((const void*)k_dec_cross_attn_es8<0, 5>, e8_lds(5));
+        hipLaunchKernelGGL((k_dec_cross_attn_es8<0, 5>), dim3(grid), dim3(320), e8_lds(5), s, qe, (const unsigned char*)E, (bf16*)out, S, e_rows, mpad, B);
+    }
+}
+
+void wh_launch_layernorm_es8(hipStream_t s, const float* x, const float* gamma, const float* beta, void* out, long rows, int S, int e_rows) {
+    hipLaunchKernelGGL(k_layernorm_es8, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, gamma, beta, (unsigned char*)out, rows, S, e_rows);
+}

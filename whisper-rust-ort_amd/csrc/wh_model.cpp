@@ -682,6 +682,9 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     std::vector<float> ckvb(Ld * 2 * d, 0.0f);
     std::vector<float> ckvsc(Ld * 2 * d, 1.0f);
     std::vector<uint8_t> ckv8(f8 ? Ld * 2 * d * d : 0);   // WH_PREC_FP8: the stacked cross K/V projection rows as raw e4m3 codes
+    // WH_PREC_FP8 on whisper-base geometry: contexts of 256 clips and more attend over e4m3 encoder states (wh_cross_es8.hip)
+    const bool es8 = f8 && wh_cross_es_geometry(c.d_model, c.n_heads, c.n_audio_ctx) && getenv("WH_NO_ES8") == nullptr;
+    std::vector<std::vector<float>> deq_k(es8 ? Ld : 0), deq_v(es8 ? Ld : 0);
     for (int i = 0; i < c.dec_layers; i++) {
         std::string p = dd + ".layers." + std::to_string(i);
         DecOff& x = dof[i];
@@ -713,6 +716,15 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
             QRows qk, qv;
             qrows(T(p + ".encoder_attn.k_proj.weight"), d, d, 1.0f, qk, 0, d);
             qrows(T(p + ".encoder_attn.v_proj.weight"), d, d, 1.0f, qv, 0, d);
+            if (es8) {   // the quantised model's own W_k and W_v (code x row scale) for the encoder-state form, below
+                deq_k[i].resize(d * d);
+                deq_v[i].resize(d * d);
+                for (size_t r = 0; r < d; r++)
+                    for (size_t k = 0; k < d; k++) {
+                        deq_k[i][r * d + k] = wh_e4m3_to_f32(qk.codes[r * d + k]) * qk.scale[r];
+                        deq_v[i][r * d + k] = wh_e4m3_to_f32(qv.codes[r * d + k]) * qv.scale[r];
+                    }
+            }
             for (size_t r = 0; r < d; r++) {
                 std::vector<float> rowk(d), rowv(d);
                 for (size_t k = 0; k < d; k++) { rowk[k] = wh_e4m3_to_f32(qk.codes[r * d + k]); rowv[k] = wh_e4m3_to_f32(qv.codes[r * d + k]); }
@@ -774,14 +786,16 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     //   out[64 h + t] = sum_j Wv[64 h + t][j] ctx[h][j] + bv[64 h + t]   (grouped decode GEMM) -> the plain W_v rows and b_v of the stacked
     //   cross-K/V projection (cross_kv_w / cross_kv_b), which stay on the device for the contexts that project K and V
     // The query projection (LN2 folded, pre-scaled) and the out-projection are the ones the K / V form uses.
-    std::vector<size_t> o_cqx(c.dec_layers, NONE);
-    // (WH_PREC_F16X3: the same, with both matrices as fp16 limbs)
-    const bool cross_es = (m->prec == WH_PREC_BF16 || x3) && wh_cross_es_geometry(c.d_model, c.n_heads, c.n_audio_ctx);
+    std::vector<size_t> o_cqx(c.dec_layers, NONE), o_cvx(c.dec_layers, NONE);
+    // (WH_PREC_F16X3: the same, with both matrices as fp16 limbs.  WH_PREC_FP8, wh_cross_es8.hip: the states are e4m3 and the two matrices are the
+    // quantised model's own W_k / W_v — code x row scale — as bf16: the expansion and the per-head V product run on the bf16 kernels)
+    const bool cross_es = (m->prec == WH_PREC_BF16 || x3 || es8) && wh_cross_es_geometry(c.d_model, c.n_heads, c.n_audio_ctx);
     if (cross_es) {
         const size_t H = c.n_heads, HD = WH_HEAD_DIM;
         std::vector<float> wkT(H * d * HD);
         for (int i = 0; i < c.dec_layers; i++) {
-            const float* Wk = T(dd + ".layers." + std::to_string(i) + ".encoder_attn.k_proj.weight");
+            const float* Wk = es8 ? deq_k[i].data() : T(dd + ".layers." + std::to_string(i) + ".encoder_attn.k_proj.weight");
+            if (es8) o_cvx[i] = st.put_mat(deq_v[i].data(), d, d, d);
             for (size_t h = 0; h < H; h++)
                 for (size_t j = 0; j < d; j++)
                     for (size_t t = 0; t < HD; t++) wkT[(h * d + j) * HD + t] = Wk[(h * HD + t) * d + j];
@@ -885,7 +899,7 @@ int wh_model_build(const wh_dims& c, std::vector<float>&& master_in, int device,
     if (cross_es)
         for (int i = 0; i < c.dec_layers; i++) {
             m->dec[i].cqx_w = P(o_cqx[i]);
-            m->dec[i].cv_w = (char*)P(o_ckv) + ((size_t)i * 2 + 1) * d * d * m->esz;
+            m->dec[i].cv_w = o_cvx[i] != NONE ? (void*)P(o_cvx[i]) : (void*)((char*)P(o_ckv) + ((size_t)i * 2 + 1) * d * d * m->esz);
             m->dec[i].cv_b = PF(o_ckvb) + ((size_t)i * 2 + 1) * d;
         }
     m->cross_es = cross_es;
