@@ -598,7 +598,9 @@ def main() -> None:
 
     if rank == 0:
         cross_es = cross_es_mode
-        work = algorithmic_work(dims, per_stream, len(prompt), a.max_new_tokens, 1 if prec == wb.WH_PREC_FP8 else esz, cross_es)
+        # bytes per element of what the cross-attention streams: e4m3 (fp8 mode), fp16 + e4m3 remainder (split-fp16 mode on the encoder states, unless WH_ES3=0), else the compute dtype
+        es3 = cross_es and prec == wb.WH_PREC_F16X3 and os.environ.get("WH_ES3", "1") != "0"
+        work = algorithmic_work(dims, per_stream, len(prompt), a.max_new_tokens, 1 if prec == wb.WH_PREC_FP8 else 3 if es3 else esz, cross_es)
         audio_s = 30.0 * a.clips * a.steps * world
         ms_per_step = elapsed / a.steps * 1e3
         # Roofline of the dominant kernel (the decoder cross-attention: largest single-kernel share in every rocprofv3 --stats
@@ -613,7 +615,7 @@ def main() -> None:
         traffic = None
         traffic_stamp = None
         # the dominant kernel's variants: e4m3 cache (fp8 mode), one workgroup per 256-column group (wide models), all heads per workgroup
-        dom_kernel = ("k_dec_cross_attn_es2" if (cross_es and prec == wb.WH_PREC_F16X3) else "k_dec_cross_attn_es8" if (cross_es and prec == wb.WH_PREC_FP8) else
+        dom_kernel = ("k_dec_cross_attn_es3" if es3 else "k_dec_cross_attn_es2" if (cross_es and prec == wb.WH_PREC_F16X3) else "k_dec_cross_attn_es8" if (cross_es and prec == wb.WH_PREC_FP8) else
                       "k_dec_cross_attn_es" if cross_es else "k_dec_cross_attn8" if prec == wb.WH_PREC_FP8 else
                       "k_dec_cross_attn_cg" if (prec == wb.WH_PREC_BF16 and dims.d_model > 512 and dims.d_model % 256 == 0) else "k_dec_cross_attn")
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -8,6 +8,7 @@ Tolerances
   exceeds the measured logit error bound (teacher-forced), see test_bf16_*.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -412,6 +413,36 @@ def test_workspace_placement_step(gpu, monkeypatch):
     off.close()
     # bf16 rows of a 4-clip context (k_gemm small-context kernels, no fold) and of a 1024-clip one differ in rounding: compare the prompt echo and lengths only
     assert all(g[:4] == r[:4] and len(g) == len(r) for g, r in zip(got, ref))
+
+
+def test_split_fp16_encoder_state_kernels(gpu, golden_dir):
+    """The split-fp16 mode's cross-attention streams the encoder states as fp16 + an e4m3 remainder (k_dec_cross_attn_es3, 3 bytes per element; every
+    f16x3 test of this file at 256 clips and more runs it).  Here: the kernel alone against a host restatement (tools/es3_check), and the form it
+    replaced — two fp16 limbs, k_dec_cross_attn_es2, WH_ES3=0 — still held to the golden vectors, in a process of its own (the switch is read once)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "es3_check")
+    assert os.path.exists(exe), f"{exe} missing: __graft_entry__.build() compiles it"
+    r = subprocess.run([exe, "64"], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0 and "MISMATCH" not in r.stdout, r.stdout + r.stderr
+    code = (
+        "import os, sys, numpy as np\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from whisper_rust_ort_amd import binding as wb, modelspec as ms\n"
+        f"g = np.load(os.path.join({golden_dir!r}, 'base_s1234_c0.npz'))\n"
+        "prompt, eot, forced = g['prompt'].tolist(), int(g['eot']), g['forced_c'].tolist()\n"
+        "m = wb.Model('synthetic:base:1234', 0, wb.WH_PREC_F16X3)\n"
+        "c = wb.Context(m, 256)\n"
+        "c.transcribe_batch([ms.synth_clip(0)] + [ms.synth_clip(300 + i) for i in range(255)], wb.DecodeParams(prompt, 2, eot, [eot]))\n"
+        "_, lg = c.greedy_decode_resident_rows(wb.DecodeParams(prompt, len(forced) + 1, eot, forced=forced), [0])\n"
+        "err = max(float(np.abs(lg[0][i][g['top_ids_c'][i]] - g['top_vals_c'][i]).max()) for i in range(len(forced) + 1))\n"
+        "print('es2 form: max |logit - golden|', err)\n"
+        "assert err < 1e-3, err\n")
+    env = dict(os.environ, WH_ES3="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    print(r.stdout, r.stderr[-400:])
+    assert r.returncode == 0, r.stdout + r.stderr
 
 
 def test_bf16_batch_is_deterministic_and_permutation_invariant(gpu):

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libwhisper_hip.so")
-SOURCES = ["wh_mel.hip", "wh_gemm.hip", "wh_gemm8.hip", "wh_gemm8x.hip", "wh_gemm8_mx.hip", "wh_mlp.hip", "wh_attn.hip", "wh_decode.hip", "wh_dec_tile.hip", "wh_cross_es.hip", "wh_cross_es8.hip", "wh_fp8.hip", "wh_model.cpp", "wh_api.cpp"]
+SOURCES = ["wh_mel.hip", "wh_gemm.hip", "wh_gemm8.hip", "wh_gemm8x.hip", "wh_gemm8_mx.hip", "wh_mlp.hip", "wh_attn.hip", "wh_decode.hip", "wh_dec_tile.hip", "wh_cross_es.hip", "wh_cross_es8.hip", "wh_cross_es3.hip", "wh_fp8.hip", "wh_model.cpp", "wh_api.cpp"]
 HEADERS = ["wh_common.h", "wh_kernels.h", "wh_internal.h", "wh_json.h", "../../include/whisper_hip.h"]
 # -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx950's register file is unified).  With the default
 # heuristic the attention kernel kept its score and output tiles in AGPRs and spent 160 of ~400 VALU instructions
@@ -21,7 +21,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-pthread", "-Wa
 # wh_attn.hip: the softmax maxima never see a NaN that matters (a NaN score poisons its row either way); without
 # this every fmaxf operand is canonicalised first (v_max_f32 x, x, x), which doubles the max instructions of a loop
 # that is VALU-bound.  Infinities keep their meaning (-inf masks the tail keys).
-EXTRA_FLAGS = {"wh_attn.hip": ["-fno-honor-nans"], "wh_cross_es.hip": ["-fno-honor-nans"], "wh_cross_es8.hip": ["-fno-honor-nans"]}   # (the same for the running maxima of wh_cross_es.hip)
+EXTRA_FLAGS = {"wh_attn.hip": ["-fno-honor-nans"], "wh_cross_es.hip": ["-fno-honor-nans"], "wh_cross_es8.hip": ["-fno-honor-nans"], "wh_cross_es3.hip": ["-fno-honor-nans"]}   # (the same for the running maxima of wh_cross_es.hip)
 
 
 def _stale(target: str, deps) -> bool:
@@ -66,7 +66,7 @@ def build_tools(verbose: bool = False, force: bool = False) -> None:
     """Device-side check binaries the GPU tests run (tests/test_fp8_gpu.py, tests/test_hip_parity.py): the MX MFMA layout probe, the MX GEMM /
     LayerNorm kernels and the one-launch feed-forward block (k_enc_mlp) against host restatements.  They include the library's kernel source directly."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    for name, kernel_src in (("mx_mfma_check", "wh_gemm8_mx.hip"), ("mx_gemm_check", "wh_gemm8_mx.hip"), ("mlp_check", "wh_mlp.hip"), ("es8_check", "wh_cross_es8.hip")):
+    for name, kernel_src in (("mx_mfma_check", "wh_gemm8_mx.hip"), ("mx_gemm_check", "wh_gemm8_mx.hip"), ("mlp_check", "wh_mlp.hip"), ("es8_check", "wh_cross_es8.hip"), ("es3_check", "wh_cross_es3.hip")):
         src, exe = os.path.join(TOOLS, name + ".hip"), os.path.join(TOOLS, name)
         deps = [src, os.path.join(CSRC, kernel_src), os.path.join(CSRC, "wh_common.h"), os.path.join(CSRC, "wh_kernels.h")]
         if force or _stale(exe, deps):

@@ -779,6 +779,7 @@ void wh_launch_dec_cross_attn_es(hipStream_t s, int prec, const float* qe, const
     static const int nl = [] { const char* e = getenv("WH_ES_LOADERS"); return e ? atoi(e) : 1; }();        // (A/B runs) loader waves per workgroup
     static const int persist = [] { const char* e = getenv("WH_ES_PERSIST"); return e ? atoi(e) : 1; }();   // (A/B runs) 0: one workgroup per clip
     if (prec == WH_PREC_FP8) { wh_launch_dec_cross_attn_es8(s, qe, E, out, S, e_rows, B, mpad, stream_nt, n_cus); return; }   // e4m3 states (wh_cross_es8.hip)
+    if (prec == WH_PREC_F16X3 && wh_es3_enabled()) { wh_launch_dec_cross_attn_es3(s, qe, E, out, S, e_rows, B, mpad, stream_nt, n_cus); return; }   // fp16 + e4m3 remainder (wh_cross_es3.hip)
     if (n_cus <= 0) n_cus = 256;   // (the context passes the population of its decode stream's CU mask, else its device's CU count)
     if (nt_env >= 0) stream_nt = nt_env != 0;
     const int grid = persist ? std::min(B, n_cus) : B;   // one workgroup per CU walks its clips

@@ -238,6 +238,11 @@ void wh_launch_dec_qexpand(hipStream_t s, int prec, const float* q, const void* 
 // e_rows >= S: rows between two clips' states; n_cus: compute units the launch stream may use (one persistent workgroup per CU)
 void wh_launch_dec_cross_attn_es(hipStream_t s, int prec, const float* qe, const void* E, void* out, int S, int e_rows, int B, int mpad, bool stream_nt, int n_cus);
 void wh_launch_layernorm_es2(hipStream_t s, const float* x, const float* w, const float* b, void* y, long rows, int in_blk, int out_blk);
+// (WH_PREC_F16X3, wh_cross_es3.hip: E as key rows of [d fp16 | d e4m3 remainders] = 3 bytes per element, written by wh_launch_layernorm_es3; the default of the
+// mode — wh_es3_enabled(), WH_ES3=0 keeps the two-fp16-limb form — and dispatched by wh_launch_dec_cross_attn_es)
+bool wh_es3_enabled();
+void wh_launch_dec_cross_attn_es3(hipStream_t s, const float* qe, const void* E, void* out, int S, int e_rows, int B, int mpad, bool stream_nt, int n_cus);
+void wh_launch_layernorm_es3(hipStream_t s, const float* x, const float* w, const float* b, void* y, long rows, int in_blk, int out_blk);
 // (WH_PREC_FP8, wh_cross_es8.hip: E as e4m3 rows [B][e_rows][d] written by wh_launch_layernorm_es8; wkT and out as in bf16 — wh_launch_dec_cross_attn_es dispatches on prec)
 void wh_launch_dec_cross_attn_es8(hipStream_t s, const float* qe, const void* E, void* out, int S, int e_rows, int B, int mpad, bool stream_nt, int n_cus);
 void wh_launch_layernorm_es8(hipStream_t s, const float* x, const float* gamma, const float* beta, void* out, long rows, int S, int e_rows);
