@@ -62,8 +62,8 @@ __device__ __forceinline__ long e8_join(unsigned lo, unsigned hi) { return (long
 
 // qe : [B][8][512] f32 expanded queries (natural-log score units)        E: [B][e_rows][512] e4m3 encoder states (final LayerNorm applied)
 // out: ctx as the decode GEMM's operand, slab layout [8 * 512 / 32][mpad][32] bf16, column h * 512 + dim
-template <int AUX, int NSTAGE>
-__global__ __launch_bounds__(320, 1) void k_dec_cross_attn_es8(const float* __restrict__ qe, const unsigned char* __restrict__ E, bf16* __restrict__ out,
+template <int AUX, int NSTAGE, int NL>
+__global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es8(const float* __restrict__ qe, const unsigned char* __restrict__ E, bf16* __restrict__ out,
                                                                 int S, int e_rows, int mpad, int B) {
     constexpr int LA = NSTAGE - 1;   // LA tiles staged ahead of the one being consumed
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -78,14 +78,17 @@ __global__ __launch_bounds__(320, 1) void k_dec_cross_attn_es8(const float* __re
 
     if (wave >= 4) {
         // ================================ loader ================================
-        constexpr int PPT = E8_TILEB / 1024;   // 16 pieces of 1 KiB = 2 key rows per tile
+        constexpr int PPT = E8_TILEB / 1024 / NL;   // pieces of 1 KiB = 2 key rows per tile and loader wave (an LDS-DMA piece costs its issuer ~100 cycles:
+                                                    // one wave issuing all 16 takes longer than the 1,350 cycles a tile has at the HBM rate)
+        const int lw = wave - 4;
         const int rsub = lane >> 5, pc = lane & 31;   // row inside a piece, physical 16-byte chunk of the row
         int st_clip = blockIdx.x, st_t = 0, st_slot = 0;   // tiles are staged strictly in sequence
         auto stage_next = [&]() {
             char* base = smem + st_slot * E8_TILEB;
             const unsigned char* Ec = E + (long)st_clip * e_rows * E8_ROWB;
 #pragma unroll
-            for (int j = 0; j < PPT; j++) {
+            for (int jj = 0; jj < PPT; jj++) {
+                const int j = lw * PPT + jj;
                 const int r = 2 * j + rsub;
                 const int key = min(st_t * E8_TK + r, S - 1);   // rows past the clip's end re-read its last key (finite; their scores are masked)
                 e8_glds16<AUX>(Ec + (long)key * E8_ROWB + ((pc ^ e8_swz(r)) << 4), base + j * 1024);
@@ -93,10 +96,14 @@ __global__ __launch_bounds__(320, 1) void k_dec_cross_attn_es8(const float* __re
             st_slot = st_slot + 1 == NSTAGE ? 0 : st_slot + 1;
             if (++st_t == ntile) { st_t = 0; st_clip += G; }
         };
+        constexpr int QPP = 16 / NL;
         auto stage_q = [&](int clip) {
             const float* src = qe + (long)clip * (E8_H * E8_D);
 #pragma unroll
-            for (int j = 0; j < 16; j++) e8_glds16<0>(src + (j * 64 + lane) * 4, reinterpret_cast<char*>(Qs) + j * 1024);
+            for (int jj = 0; jj < QPP; jj++) {
+                const int j = lw * QPP + jj;
+                e8_glds16<0>(src + (j * 64 + lane) * 4, reinterpret_cast<char*>(Qs) + j * 1024);
+            }
         };
         stage_q(blockIdx.x);
 #pragma unroll
@@ -340,15 +347,18 @@ __global__ __launch_bounds__(256) void k_layernorm_es8(const float* __restrict__
 
 // (two workgroups per CU with rings of three tiles were measured: 419 vs 324 us per 2048-clip launch — the shallow rings starve the stream)
 void wh_launch_dec_cross_attn_es8(hipStream_t s, const float* qe, const void* E, void* out, int S, int e_rows, int B, int mpad, bool stream_nt, int n_cus) {
+    // (A/B runs) loader waves per workgroup — measured in the pipeline at 2048 clips (tools/runs/gpu_r04ao.sh): no difference (214.6 vs 215.6 ms of cross-attention), so one
+    static const int nl = [] { const char* e = getenv("WH_ES8_LOADERS"); return e ? atoi(e) : 1; }();
     if (n_cus <= 0) n_cus = 256;
     const int grid = std::min(B, n_cus);   // one workgroup per CU walks its clips
-    if (stream_nt) {
-        wh_ensure_dyn_lds((const void*)k_dec_cross_attn_es8<2, 5>, e8_lds(5));
-        hipLaunchKernelGGL((k_dec_cross_attn_es8<2, 5>), dim3(grid), dim3(320), e8_lds(5), s, qe, (const unsigned char*)E, (bf16*)out, S, e_rows, mpad, B);
-    } else {
-        wh_ensure_dyn_lds((const void*)k_dec_cross_attn_es8<0, 5>, e8_lds(5));
-        hipLaunchKernelGGL((k_dec_cross_attn_es8<0, 5>), dim3(grid), dim3(320), e8_lds(5), s, qe, (const unsigned char*)E, (bf16*)out, S, e_rows, mpad, B);
-    }
+#define WH_ES8_LAUNCH(AUX_, NL_)                                                                                                                         \
+    do {                                                                                                                                                 \
+        wh_ensure_dyn_lds((const void*)k_dec_cross_attn_es8<AUX_, 5, NL_>, e8_lds(5));                                                                   \
+        hipLaunchKernelGGL((k_dec_cross_attn_es8<AUX_, 5, NL_>), dim3(grid), dim3(256 + 64 * NL_), e8_lds(5), s, qe, (const unsigned char*)E, (bf16*)out, S, e_rows, mpad, B); \
+    } while (0)
+    if (stream_nt) { if (nl == 1) WH_ES8_LAUNCH(2, 1); else WH_ES8_LAUNCH(2, 2); }
+    else { if (nl == 1) WH_ES8_LAUNCH(0, 1); else WH_ES8_LAUNCH(0, 2); }
+#undef WH_ES8_LAUNCH
 }
 
 void wh_launch_layernorm_es8(hipStream_t s, const float* x, const float* gamma, const float* beta, void* out, long rows, int S, int e_rows) {
