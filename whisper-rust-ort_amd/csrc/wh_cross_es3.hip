@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void k_layernorm_es3(const float* __restrict__
     f16x8 hi;
     float rm[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) { hi[e] = (_Float16)o[e]; rm[e] = (o[e] - (float)hi[e]) * 4096.0f; }
+    for (int e = 0; e < 8; e++) { hi[e] = (_Float16)o[e]; rm[e] = fminf(fmaxf((o[e] - (float)hi[e]) * 4096.0f, -448.0f), 448.0f); }   // (|o| < 256 never reaches the clamp)
     const long orow = in_blk > 0 ? (row / in_blk) * out_blk + row % in_blk : row;
     unsigned char* yr = y + orow * E3_ROWB;
     *reinterpret_cast<f16x8*>(yr + c * 2) = hi;

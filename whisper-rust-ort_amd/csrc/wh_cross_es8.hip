@@ -338,6 +338,8 @@ __global__ __launch_bounds__(256) void k_layernorm_es8(const float* __restrict__
     float v[8];
 #pragma unroll
     for (int u = 0; u < 4; u++) { v[u] = (a[u] - mean) * rstd * g0[u] + c0[u]; v[4 + u] = (b[u] - mean) * rstd * g1[u] + c1[u]; }
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = fminf(fmaxf(v[u], -448.0f), 448.0f);   // e4m3's range (a LayerNorm output of that size would be an outlier of outliers; never a NaN code)
     const wh_u32x2 o = {e8_pack4(v[0], v[1], v[2], v[3]), e8_pack4(v[4], v[5], v[6], v[7])};
     const long clip = r / S, key = r % S;
     *reinterpret_cast<wh_u32x2*>(out + (clip * e_rows + key) * E8_D + lane * 8) = o;
