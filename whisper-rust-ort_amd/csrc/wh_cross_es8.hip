@@ -347,7 +347,9 @@ __global__ __launch_bounds__(256) void k_layernorm_es8(const float* __restrict__
 
 }  // namespace
 
-// (two workgroups per CU with rings of three tiles were measured: 419 vs 324 us per 2048-clip launch — the shallow rings starve the stream)
+// (two workgroups per CU were measured twice: with rings of three tiles 419 vs 324 us per 2048-clip launch on random data — the shallow rings starve the stream;
+// with rings of four and the queries read from global memory instead of an LDS prefetch buffer 215 vs 200 ms of cross-attention per step in the pipeline,
+// tools/runs/gpu_r04as.sh — one workgroup per CU stays)
 void wh_launch_dec_cross_attn_es8(hipStream_t s, const float* qe, const void* E, void* out, int S, int e_rows, int B, int mpad, bool stream_nt, int n_cus) {
     // (A/B runs) loader waves per workgroup — measured in the pipeline at 2048 clips (tools/runs/gpu_r04ao.sh): no difference (214.6 vs 215.6 ms of cross-attention), so one
     static const int nl = [] { const char* e = getenv("WH_ES8_LOADERS"); return e ? atoi(e) : 1; }();
