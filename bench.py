@@ -595,6 +595,30 @@ def main() -> None:
                               "(measured 5e-5) like the exact-f32 MFMA mode beside it"}
         except Exception as e:
             in_tol = {"error": f"{type(e).__name__}: {e}"}
+    # ---- BASELINE configs[4]'s precision on the same clips, in the same run (bf16 headline only): e4m3 weights, MX activations, cross-attention on e4m3 encoder states
+    fp8_side = None
+    if rank == 0 and world == 1 and not a.no_batch1 and prec == wb.WH_PREC_BF16 and a.preset == "base":
+        try:
+            for cx in ctxs:
+                cx.close()
+            ctxs = []
+            m8 = wb.Model(f"synthetic:{a.preset}:{a.seed}", dev, wb.WH_PREC_FP8)
+            c8 = wb.Context(m8, a.clips)
+            c8.transcribe_batch_device(d_pcm, a.clips, params)
+            hip.sync()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                c8.transcribe_batch_device(d_pcm, a.clips, params)
+            hip.sync()
+            e8 = (time.perf_counter() - t1) / 3
+            tm8 = c8.timings()
+            fp8_side = {"dtype": "fp8", "clips_per_step": a.clips, "steps": 3, "ms_per_step": e8 * 1e3, "rtfx": 30.0 * a.clips / e8,
+                        "cross_mode": c8.cross_mode, "stage_ms": {k: tm8[k] * 1e3 for k in ("preprocess_s", "encode_s", "decode_s")},
+                        "note": "WH_PREC_FP8 (BASELINE configs[4]): e4m3 weights, MX activations on the fp8 matrix cores in the encoder, the token loop's cross-attention on "
+                                "e4m3 encoder states (k_dec_cross_attn_es8); accuracy: profiles/r04_accuracy_64clips.json, tests/test_fp8_gpu.py"}
+            c8.close()
+        except Exception as e:
+            fp8_side = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         cross_es = cross_es_mode
@@ -696,6 +720,7 @@ def main() -> None:
             "host_resident": host_res,
             "workspace_placement": placement,
             "in_tolerance": in_tol,
+            "fp8": fp8_side,
             "scaling_weak": {"clips_per_gpu": a.clips, "total_clips_per_step": a.clips * world, "ms_per_step": ms_per_step, "value": audio_s / elapsed} if scaling == "weak" else None,
             "scaling_strong": strong if scaling == "weak" else {"total_clips_per_step": a.clips * world, "clips_per_gpu": a.clips, "ms_per_step": ms_per_step, "value": audio_s / elapsed},
             "stage_ms_per_step": {k: v / a.steps * 1e3 for k, v in stage.items()},
