@@ -27,7 +27,7 @@ __global__ void k_pack_es3(const float* __restrict__ x, unsigned char* __restric
     for (int e = 0; e < 8; e++) { const float o = x[row * 512 + c + e]; hi[e] = (_Float16)o; rm[e] = (o - (float)hi[e]) * 4096.0f; }
     unsigned char* yr = y + row * E3_ROWB;
     *reinterpret_cast<f16x8*>(yr + c * 2) = hi;
-    *reinterpret_cast<wh_u32x2*>(yr + 1024 + c) = wh_u32x2{e3_pack4(rm[0], rm[1], rm[2], rm[3]), e3_pack4(rm[4], rm[5], rm[6], rm[7])};
+    *reinterpret_cast<wh_u32x2*>(yr + 1024 + c) = wh_u32x2{pack4(rm[0], rm[1], rm[2], rm[3]), pack4(rm[4], rm[5], rm[6], rm[7])};
 }
 
 static int check(int B, int S, int n_cus) {

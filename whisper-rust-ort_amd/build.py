@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libwhisper_hip.so")
 SOURCES = ["wh_mel.hip", "wh_gemm.hip", "wh_gemm8.hip", "wh_gemm8x.hip", "wh_gemm8_mx.hip", "wh_mlp.hip", "wh_attn.hip", "wh_decode.hip", "wh_dec_tile.hip", "wh_cross_es.hip", "wh_cross_es8.hip", "wh_cross_es3.hip", "wh_fp8.hip", "wh_model.cpp", "wh_api.cpp"]
-HEADERS = ["wh_common.h", "wh_kernels.h", "wh_internal.h", "wh_json.h", "../../include/whisper_hip.h"]
+HEADERS = ["wh_common.h", "wh_es_fp8.h", "wh_kernels.h", "wh_internal.h", "wh_json.h", "../../include/whisper_hip.h"]
 # -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx950's register file is unified).  With the default
 # heuristic the attention kernel kept its score and output tiles in AGPRs and spent 160 of ~400 VALU instructions
 # per key tile on v_accvgpr_read/write copies around the softmax.

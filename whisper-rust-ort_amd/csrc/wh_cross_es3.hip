@@ -21,12 +21,12 @@
 #include <algorithm>
 
 #include "wh_common.h"
+#include "wh_es_fp8.h"
 #include "wh_kernels.h"
 
 namespace {
 
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
+using namespace wh_es_fp8;
 
 constexpr int E3_D = 512, E3_H = 8, E3_TK = 32, E3_NSTAGE = 3;
 constexpr int E3_ROWB = E3_D * 3;                      // bytes per key row in memory: 1 KiB of fp16, 512 B of e4m3
@@ -36,28 +36,7 @@ constexpr int E3_SCP = 36;                             // floats per (dim half, 
 constexpr int E3_SCB = 4 * E3_H * E3_SCP;              // floats per score-exchange buffer
 constexpr int E3_LDS = E3_NSTAGE * E3_TILEB + 2 * E3_SCB * 4;   // 153 KiB
 constexpr float E3_S8 = 1.0f / 4096.0f;                // the e4m3 plane's weight (states' remainders are stored x 2^12)
-constexpr float E3_REM = 16.0f, E3_REM_INV = 1.0f / 16.0f;   // scale of the e4m3 remainder rows of queries and probabilities
 
-template <int N> __device__ __forceinline__ void e3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-template <int AUX>
-__device__ __forceinline__ void e3_glds16(const void* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, AUX);
-}
-__device__ __forceinline__ int e3_swz8(int r) { return (r & 15) ^ (((r >> 4) & 1) << 3); }   // e4m3 rows (wh_cross_es8.hip)
-__device__ __forceinline__ float e3_ror8(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
-}
-__device__ __forceinline__ unsigned e3_ror8u(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true); }
-__device__ __forceinline__ unsigned e3_pack4(float a, float b, float c, float d) {
-    int p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
-}
-__device__ __forceinline__ unsigned e3_rem4(unsigned hi, float a, float b, float c, float d) {
-    const float h0 = __builtin_amdgcn_cvt_f32_fp8((int)hi, 0), h1 = __builtin_amdgcn_cvt_f32_fp8((int)hi, 1);
-    const float h2_ = __builtin_amdgcn_cvt_f32_fp8((int)hi, 2), h3 = __builtin_amdgcn_cvt_f32_fp8((int)hi, 3);
-    return e3_pack4((a - h0) * E3_REM, (b - h1) * E3_REM, (c - h2_) * E3_REM, (d - h3) * E3_REM);
-}
-__device__ __forceinline__ long e3_join(unsigned lo, unsigned hi) { return (long)(((unsigned long long)hi << 32) | lo); }
 // two fp16 as one dword (lo half = a)
 __device__ __forceinline__ unsigned e3_h2(float a, float b) {
     typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
@@ -94,14 +73,14 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es3(const f
             for (int jj = 0; jj < E3_TK / NL; jj++) {   // fp16 rows: a piece is one key's 1 KiB, LDS chunk p holds dim-chunk p ^ (r & 15)
                 const int j = lw * (E3_TK / NL) + jj;
                 const int key = min(st_t * E3_TK + j, S - 1);   // rows past the clip's end re-read its last key (finite; their scores are masked)
-                e3_glds16<AUX>(Ec + (long)key * E3_ROWB + ((lane ^ (j & 15)) << 4), base + j * 1024);
+                glds16<AUX>(Ec + (long)key * E3_ROWB + ((lane ^ (j & 15)) << 4), base + j * 1024);
             }
 #pragma unroll
             for (int jj = 0; jj < E3_TK / 2 / NL; jj++) {   // e4m3 rows: a piece is two keys' 512 bytes
                 const int j = lw * (E3_TK / 2 / NL) + jj;
                 const int r = 2 * j + (lane >> 5);
                 const int key = min(st_t * E3_TK + r, S - 1);
-                e3_glds16<AUX>(Ec + (long)key * E3_ROWB + 2 * E3_D + (((lane & 31) ^ e3_swz8(r)) << 4), base + E3_LO + j * 1024);
+                glds16<AUX>(Ec + (long)key * E3_ROWB + 2 * E3_D + (((lane & 31) ^ swz8(r)) << 4), base + E3_LO + j * 1024);
             }
         st_slot = st_slot + 1 == NSTAGE ? 0 : st_slot + 1;
             if (++st_t == ntile) { st_t = 0; st_clip += G; }
@@ -109,10 +88,10 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es3(const f
 #pragma unroll
         for (int t = 0; t < LA; t++)
             if (t < total) stage_next();
-        if (total >= LA) e3_wait_vm<48 / NL>(); else e3_wait_vm<0>();   // tile 0 (the older of two) has landed
+        if (total >= LA) wait_vm<48 / NL>(); else wait_vm<0>();   // tile 0 (the older of two) has landed
         __builtin_amdgcn_s_barrier();   // P: tile 0 is in the ring
         for (int g = 0; g < total; g++) {
-            if (g + 1 < total) e3_wait_vm<0>();   // tile g + 1 has landed (nothing younger is in flight at this point)
+            if (g + 1 < total) wait_vm<0>();   // tile g + 1 has landed (nothing younger is in flight at this point)
             __builtin_amdgcn_s_barrier();
             if (g + LA < total) stage_next();
         }
@@ -147,9 +126,9 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es3(const f
 #pragma unroll
                 for (int u = 0; u < 8; u++) { h[u] = (_Float16)v[u]; r[u] = (_Float16)(v[u] - (float)h[u]); }
                 qa16[s0 + s] = lo ? r : h;
-                const unsigned h0 = e3_pack4(v[0], v[1], v[2], v[3]), h1 = e3_pack4(v[4], v[5], v[6], v[7]);
-                const unsigned r0 = e3_rem4(h0, v[0], v[1], v[2], v[3]), r1 = e3_rem4(h1, v[4], v[5], v[6], v[7]);
-                qa8[s0 + s] = lo ? e3_join(r0, r1) : e3_join(h0, h1);
+                const unsigned h0 = pack4(v[0], v[1], v[2], v[3]), h1 = pack4(v[4], v[5], v[6], v[7]);
+                const unsigned r0 = rem4(h0, v[0], v[1], v[2], v[3]), r1 = rem4(h1, v[4], v[5], v[6], v[7]);
+                qa8[s0 + s] = lo ? join(r0, r1) : join(h0, h1);
             }
         }
     };
@@ -160,7 +139,7 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es3(const f
 #pragma unroll
         for (int s = 0; s < 8; s++) e16[s] = *reinterpret_cast<const f16x8*>(rp16 + (((32 * hf + 4 * s + fg) ^ (r & 15)) << 4));
     };
-    const float w8 = fg < 2 ? E3_S8 : E3_S8 * E3_REM_INV;   // weight of this lane's rows of an e4m3-plane product
+    const float w8 = fg < 2 ? E3_S8 : E3_S8 * REM_INV;   // weight of this lane's rows of an e4m3-plane product
     auto score_mfma = [&](int sl, const f16x8 (&e16)[8], int buf) {
         f32x4 d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0}, c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
 #pragma unroll
@@ -171,7 +150,7 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es3(const f
         {
             const int r = 16 * kt + fl;
             const char* rp8 = smem + sl * E3_TILEB + E3_LO + r * 512 + (fg & 1) * 8;
-            const int sw = e3_swz8(r);
+            const int sw = swz8(r);
             long e8[8];
 #pragma unroll
             for (int s = 0; s < 8; s++) e8[s] = *reinterpret_cast<const long*>(rp8 + (((16 * hf + 2 * s + (fg >> 1)) ^ sw) << 4));
@@ -230,7 +209,7 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es3(const f
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) tmax = fmaxf(tmax, sv[u]);
-            tmax = fmaxf(tmax, e3_ror8(tmax));
+            tmax = fmaxf(tmax, ror8(tmax));
             tmax = xrow_max(tmax);
             const float m_new = fmaxf(m_run, tmax);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -245,13 +224,13 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es3(const f
                 const _Float16 q0 = (_Float16)pv[0], q1 = (_Float16)pv[1], q2 = (_Float16)pv[2], q3 = (_Float16)pv[3];
                 const unsigned oh0 = e3_h2((float)q0, (float)q1), oh1 = e3_h2((float)q2, (float)q3);
                 const unsigned ol0 = e3_h2(pv[0] - (float)q0, pv[1] - (float)q1), ol1 = e3_h2(pv[2] - (float)q2, pv[3] - (float)q3);
-                const unsigned xh0 = e3_ror8u(oh0), xh1 = e3_ror8u(oh1), xl0 = e3_ror8u(ol0), xl1 = e3_ror8u(ol1);
+                const unsigned xh0 = ror8u(oh0), xh1 = ror8u(oh1), xl0 = ror8u(ol0), xl1 = ror8u(ol1);
                 const wh_u32x4 w = fl < 8 ? wh_u32x4{oh0, oh1, xh0, xh1} : wh_u32x4{xl0, xl1, ol0, ol1};
                 __builtin_memcpy(&pa16, &w, 16);
-                const unsigned own_hi = e3_pack4(pv[0], pv[1], pv[2], pv[3]);
-                const unsigned own_lo = e3_rem4(own_hi, pv[0], pv[1], pv[2], pv[3]);
-                const unsigned oth_hi = e3_ror8u(own_hi), oth_lo = e3_ror8u(own_lo);
-                pa8 = fl < 8 ? e3_join(own_hi, oth_hi) : e3_join(oth_lo, own_lo);
+                const unsigned own_hi = pack4(pv[0], pv[1], pv[2], pv[3]);
+                const unsigned own_lo = rem4(own_hi, pv[0], pv[1], pv[2], pv[3]);
+                const unsigned oth_hi = ror8u(own_hi), oth_lo = ror8u(own_lo);
+                pa8 = fl < 8 ? join(own_hi, oth_hi) : join(oth_lo, own_lo);
             }
             l_run = l_run * alpha + ps;
             m_run = m_new;
@@ -299,7 +278,7 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es3(const f
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int r = kb + j;
-                blk8[j] = *reinterpret_cast<const wh_u32x2*>(tb + E3_LO + r * 512 + ((c8 ^ e3_swz8(r)) << 4) + (fl & 1) * 8);
+                blk8[j] = *reinterpret_cast<const wh_u32x2*>(tb + E3_LO + r * 512 + ((c8 ^ swz8(r)) << 4) + (fl & 1) * 8);
             }
             unsigned w[4][4];
 #pragma unroll
@@ -314,14 +293,14 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es3(const f
                 const unsigned sel = (e & 1) ? 0x07060302u : 0x05040100u;
                 const unsigned k03 = __builtin_amdgcn_perm(w[1][e >> 1], w[0][e >> 1], sel);
                 const unsigned k47 = __builtin_amdgcn_perm(w[3][e >> 1], w[2][e >> 1], sel);
-                acc8[e] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pa8, e3_join(k03, k47), acc8[e], 0, 0, 0);
+                acc8[e] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pa8, join(k03, k47), acc8[e], 0, 0, 0);
             }
         }
         slot = nslot;
         if (++t < ntile) continue;
         // ---- the clip ends: rows h and 8 + h (lanes l and l ^ 32) and the two planes are added, normalised, stored as an h2 slab
         {
-            const float lh = l_run + e3_ror8(l_run);
+            const float lh = l_run + ror8(l_run);
             const float inv = 1.0f / xrow_sum(lh);
             float ih[8];
 #pragma unroll
@@ -378,7 +357,7 @@ __global__ __launch_bounds__(256) void k_layernorm_es3(const float* __restrict__
     const long orow = in_blk > 0 ? (row / in_blk) * out_blk + row % in_blk : row;
     unsigned char* yr = y + orow * E3_ROWB;
     *reinterpret_cast<f16x8*>(yr + c * 2) = hi;
-    *reinterpret_cast<wh_u32x2*>(yr + 2 * E3_D + c) = wh_u32x2{e3_pack4(rm[0], rm[1], rm[2], rm[3]), e3_pack4(rm[4], rm[5], rm[6], rm[7])};
+    *reinterpret_cast<wh_u32x2*>(yr + 2 * E3_D + c) = wh_u32x2{pack4(rm[0], rm[1], rm[2], rm[3]), pack4(rm[4], rm[5], rm[6], rm[7])};
 }
 
 }  // namespace

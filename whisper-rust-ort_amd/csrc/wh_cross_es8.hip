@@ -22,12 +22,12 @@
 #include <algorithm>
 
 #include "wh_common.h"
+#include "wh_es_fp8.h"
 #include "wh_kernels.h"
 
 namespace {
 
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
+using namespace wh_es_fp8;
 
 constexpr int E8_D = 512, E8_H = 8, E8_TK = 32;
 constexpr int E8_ROWB = E8_D;                          // bytes per key row
@@ -35,30 +35,6 @@ constexpr int E8_TILEB = E8_TK * E8_ROWB;              // 16 KiB
 constexpr int E8_SCP = 36;                             // floats per (dim half, limb, head) row of the score exchange (32 keys + pad)
 constexpr int E8_SCB = 4 * E8_H * E8_SCP;              // floats per score-exchange buffer: [dim half][hi | lo of the query][head][E8_SCP]
 constexpr int e8_lds(int nstage) { return nstage * E8_TILEB + 2 * E8_SCB * 4 + E8_H * E8_D * 4; }   // ring + score exchange + next queries
-constexpr float E8_LO = 16.0f, E8_LO_INV = 1.0f / 16.0f;   // scale of the remainder rows
-
-template <int N> __device__ __forceinline__ void e8_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-template <int AUX>
-__device__ __forceinline__ void e8_glds16(const void* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, AUX);
-}
-__device__ __forceinline__ int e8_swz(int r) { return (r & 15) ^ (((r >> 4) & 1) << 3); }
-__device__ __forceinline__ float e8_ror8(float v) {    // v of lane ^ 8 (same 16-lane row): DPP row_ror:8
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
-}
-__device__ __forceinline__ unsigned e8_ror8u(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true); }
-// four f32 -> four e4m3 bytes (byte u = v[u]) and back
-__device__ __forceinline__ unsigned e8_pack4(float a, float b, float c, float d) {
-    int p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
-}
-// the remainder limb of four values whose head limb is `hi`: fp8(16 (v - hi))
-__device__ __forceinline__ unsigned e8_rem4(unsigned hi, float a, float b, float c, float d) {
-    const float h0 = __builtin_amdgcn_cvt_f32_fp8((int)hi, 0), h1 = __builtin_amdgcn_cvt_f32_fp8((int)hi, 1);
-    const float h2 = __builtin_amdgcn_cvt_f32_fp8((int)hi, 2), h3 = __builtin_amdgcn_cvt_f32_fp8((int)hi, 3);
-    return e8_pack4((a - h0) * E8_LO, (b - h1) * E8_LO, (c - h2) * E8_LO, (d - h3) * E8_LO);
-}
-__device__ __forceinline__ long e8_join(unsigned lo, unsigned hi) { return (long)(((unsigned long long)hi << 32) | lo); }
 
 // qe : [B][8][512] f32 expanded queries (natural-log score units)        E: [B][e_rows][512] e4m3 encoder states (final LayerNorm applied)
 // out: ctx as the decode GEMM's operand, slab layout [8 * 512 / 32][mpad][32] bf16, column h * 512 + dim
@@ -91,7 +67,7 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es8(const f
                 const int j = lw * PPT + jj;
                 const int r = 2 * j + rsub;
                 const int key = min(st_t * E8_TK + r, S - 1);   // rows past the clip's end re-read its last key (finite; their scores are masked)
-                e8_glds16<AUX>(Ec + (long)key * E8_ROWB + ((pc ^ e8_swz(r)) << 4), base + j * 1024);
+                glds16<AUX>(Ec + (long)key * E8_ROWB + ((pc ^ swz8(r)) << 4), base + j * 1024);
             }
             st_slot = st_slot + 1 == NSTAGE ? 0 : st_slot + 1;
             if (++st_t == ntile) { st_t = 0; st_clip += G; }
@@ -102,7 +78,7 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es8(const f
 #pragma unroll
             for (int jj = 0; jj < QPP; jj++) {
                 const int j = lw * QPP + jj;
-                e8_glds16<0>(src + (j * 64 + lane) * 4, reinterpret_cast<char*>(Qs) + j * 1024);
+                glds16<0>(src + (j * 64 + lane) * 4, reinterpret_cast<char*>(Qs) + j * 1024);
             }
         };
         stage_q(blockIdx.x);
@@ -110,13 +86,13 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es8(const f
         for (int t = 0; t < LA; t++)
             if (t < total) stage_next();
         // vmcnt retires in issue order (and holds at most 63): "all but the last LA - 1 tiles' pieces" covers the queries and tile 0
-        if (total >= LA) e8_wait_vm<(PPT * (LA - 1) < 63 ? PPT * (LA - 1) : 63)>(); else e8_wait_vm<0>();
+        if (total >= LA) wait_vm<(PPT * (LA - 1) < 63 ? PPT * (LA - 1) : 63)>(); else wait_vm<0>();
         __builtin_amdgcn_s_barrier();   // P1: the first clip's queries are in Qs
         __builtin_amdgcn_s_barrier();   // P2: tile 0 is in the ring
         int clip = blockIdx.x, t = 0;
         for (int g = 0; g < total; g++) {
             if (g + 1 < total) {   // tile g + 1 has landed; the younger tiles stay in flight (conservative where the next clip's queries are among them)
-                if (total - 2 - g >= LA - 2) e8_wait_vm<PPT*(LA - 2)>(); else e8_wait_vm<0>();
+                if (total - 2 - g >= LA - 2) wait_vm<PPT*(LA - 2)>(); else wait_vm<0>();
             }
             __builtin_amdgcn_s_barrier();
             if (g + LA < total) stage_next();
@@ -140,16 +116,16 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es8(const f
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) v[u] = (u < 4 ? a[u & 3] : b[u & 3]) * 1.44269504088896341f;   // scores in log2 units: p = exp2(s - m)
-            const unsigned h0 = e8_pack4(v[0], v[1], v[2], v[3]), h1 = e8_pack4(v[4], v[5], v[6], v[7]);
-            const unsigned r0 = e8_rem4(h0, v[0], v[1], v[2], v[3]), r1 = e8_rem4(h1, v[4], v[5], v[6], v[7]);
-            qa[s] = lo ? e8_join(r0, r1) : e8_join(h0, h1);
+            const unsigned h0 = pack4(v[0], v[1], v[2], v[3]), h1 = pack4(v[4], v[5], v[6], v[7]);
+            const unsigned r0 = rem4(h0, v[0], v[1], v[2], v[3]), r1 = rem4(h1, v[4], v[5], v[6], v[7]);
+            qa[s] = lo ? join(r0, r1) : join(h0, h1);
         }
     };
     // ---- scores of the tile in slot `sl` for keys 16 kt + fl over dims 256 hf ..: rows 4 fg + i of D; partials to sc buffer `buf`
     auto score_reads = [&](int sl, long (&ef)[8]) {
         const int r = 16 * kt + fl;
         const char* rp = smem + sl * E8_TILEB + r * E8_ROWB + (fg & 1) * 8;
-        const int sw = e8_swz(r);
+        const int sw = swz8(r);
 #pragma unroll
         for (int s = 0; s < 8; s++) {
             const int c = 16 * hf + 2 * s + (fg >> 1);
@@ -206,7 +182,7 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es8(const f
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int r = kb + j;
-                blk[j] = *reinterpret_cast<const wh_u32x2*>(tb + r * E8_ROWB + ((c ^ e8_swz(r)) << 4) + (fl & 1) * 8);
+                blk[j] = *reinterpret_cast<const wh_u32x2*>(tb + r * E8_ROWB + ((c ^ swz8(r)) << 4) + (fl & 1) * 8);
             }
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the reads above the arithmetic below
@@ -217,14 +193,14 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es8(const f
             float tmax = -INFINITY;
             const int key0 = t * E8_TK + kq;
 #pragma unroll
-            for (int u = 0; u < 4; u++) sv[u] = (a0[u] + b0[u]) + (a1[u] + b1[u]) * E8_LO_INV;   // two dim halves x {head limb, remainder / 16}
+            for (int u = 0; u < 4; u++) sv[u] = (a0[u] + b0[u]) + (a1[u] + b1[u]) * REM_INV;   // two dim halves x {head limb, remainder / 16}
             if (t == ntile - 1) {   // (wave-uniform) keys past the end of the clip
 #pragma unroll
                 for (int u = 0; u < 4; u++) sv[u] = (key0 + u < S) ? sv[u] : -INFINITY;
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) tmax = fmaxf(tmax, sv[u]);
-            tmax = fmaxf(tmax, e8_ror8(tmax));   // the head's other four keys of this lane group
+            tmax = fmaxf(tmax, ror8(tmax));   // the head's other four keys of this lane group
             tmax = xrow_max(tmax);               // over the four lane groups: all 32 keys of the tile
             const float m_new = fmaxf(m_run, tmax);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
@@ -237,11 +213,11 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es8(const f
             }
             // operand rows 0-7: e4m3(p) of keys kb .. kb + 7 (this lane's four and, through DPP, its partner's); rows 8-15: their remainders x 16
             {
-                const unsigned own_hi = e8_pack4(pv[0], pv[1], pv[2], pv[3]);
-                const unsigned own_lo = e8_rem4(own_hi, pv[0], pv[1], pv[2], pv[3]);
-                const unsigned oth_hi = e8_ror8u(own_hi), oth_lo = e8_ror8u(own_lo);
+                const unsigned own_hi = pack4(pv[0], pv[1], pv[2], pv[3]);
+                const unsigned own_lo = rem4(own_hi, pv[0], pv[1], pv[2], pv[3]);
+                const unsigned oth_hi = ror8u(own_hi), oth_lo = ror8u(own_lo);
                 // lane fl < 8 (row h) owns keys kb .. kb + 3, lane fl + 8 (row 8 + h) keys kb + 4 .. kb + 7
-                pa = fl < 8 ? e8_join(own_hi, oth_hi) : e8_join(oth_lo, own_lo);
+                pa = fl < 8 ? join(own_hi, oth_hi) : join(oth_lo, own_lo);
             }
             l_run = l_run * alpha + ps;
             m_run = m_new;
@@ -277,21 +253,21 @@ __global__ __launch_bounds__(256 + 64 * NL, 1) void k_dec_cross_attn_es8(const f
                 const unsigned sel = (e & 1) ? 0x07060302u : 0x05040100u;
                 const unsigned k03 = __builtin_amdgcn_perm(w[1][e >> 1], w[0][e >> 1], sel);   // keys kb .. kb + 3 of dim e
                 const unsigned k47 = __builtin_amdgcn_perm(w[3][e >> 1], w[2][e >> 1], sel);   // keys kb + 4 .. kb + 7
-                acc[e] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pa, e8_join(k03, k47), acc[e], 0, 0, 0);
+                acc[e] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pa, join(k03, k47), acc[e], 0, 0, 0);
             }
         }
         slot = nslot;
         if (++t < ntile) continue;
         // ---- the clip ends: rows h and 8 + h (lanes l and l ^ 32) are the head limb's and the remainder's share of head h — add, normalise, store
         {
-            const float lh = l_run + e8_ror8(l_run);   // the head's two key quartets
+            const float lh = l_run + ror8(l_run);   // the head's two key quartets
             const float inv = 1.0f / xrow_sum(lh);
             float ih[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) ih[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv), q));
             const bool up = fg & 1;
             const float inv4[4] = {up ? ih[4] : ih[0], up ? ih[5] : ih[1], up ? ih[6] : ih[2], up ? ih[7] : ih[3]};
-            const float wgt = fg < 2 ? 1.0f : E8_LO_INV;
+            const float wgt = fg < 2 ? 1.0f : REM_INV;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 bf16x8 ov;
@@ -340,7 +316,7 @@ __global__ __launch_bounds__(256) void k_layernorm_es8(const float* __restrict__
     for (int u = 0; u < 4; u++) { v[u] = (a[u] - mean) * rstd * g0[u] + c0[u]; v[4 + u] = (b[u] - mean) * rstd * g1[u] + c1[u]; }
 #pragma unroll
     for (int u = 0; u < 8; u++) v[u] = fminf(fmaxf(v[u], -448.0f), 448.0f);   // e4m3's range (a LayerNorm output of that size would be an outlier of outliers; never a NaN code)
-    const wh_u32x2 o = {e8_pack4(v[0], v[1], v[2], v[3]), e8_pack4(v[4], v[5], v[6], v[7])};
+    const wh_u32x2 o = {pack4(v[0], v[1], v[2], v[3]), pack4(v[4], v[5], v[6], v[7])};
     const long clip = r / S, key = r % S;
     *reinterpret_cast<wh_u32x2*>(out + (clip * e_rows + key) * E8_D + lane * 8) = o;
 }
